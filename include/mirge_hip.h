@@ -1,0 +1,155 @@
+/*
+ * mirge_hip.h -- C ABI of libmirge_hip.so: miRge's read-annotation hot path
+ * (collapse -> 5-round library cascade -> count vectors) on MI355X (gfx950).
+ *
+ * This is the drop-in boundary ("B2").  Every entry point
+ * replaces a piece of the reference driver, cited as miRge.pl:<lines>.  The
+ * reference has no in-process plug-in API; its own substitution point is the
+ * bowtie executable contract (--bowtie <exe>, miRge.pl:59, 91), which
+ * tools/mirge-bowtie keeps working on top of this library.
+ *
+ * Conventions: plain C types only; every function returning int gives 0 on
+ * success and a negative MIRGE_E_* code on failure, with a message available
+ * from mirge_last_error(); no exception or exit() crosses the ABI; the context
+ * owns every buffer it hands out (valid until the next call on that context);
+ * one context per caller thread, calls on one context are serial (the Perl
+ * driver is single-threaded).  There is NO CPU fallback: without a usable HIP
+ * device mirge_open() fails.
+ */
+#ifndef MIRGE_HIP_H
+#define MIRGE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRGE_OK            0
+#define MIRGE_E_ARG        -1   /* bad argument / call order                        */
+#define MIRGE_E_IO         -2   /* file missing or unreadable                       */
+#define MIRGE_E_HIP        -3   /* HIP runtime error (no device, out of memory ...) */
+#define MIRGE_E_FORMAT     -4   /* malformed FASTA/FASTQ, unsupported character     */
+#define MIRGE_E_LIMIT      -5   /* read longer than MIRGE_MAX_READ_LEN, too many ...*/
+
+#define MIRGE_MAX_READ_LEN 124  /* reads up to 56 nt without N use 16-byte keys;
+                                   longer reads / reads with N use 48-byte keys     */
+#define MIRGE_LIB_MIRNA    0    /* miRge.pl:94 */
+#define MIRGE_LIB_HAIRPIN  1    /* miRge.pl:95 */
+#define MIRGE_LIB_OTHER    2    /* miRge.pl:96 */
+#define MIRGE_LIB_MRNA     3    /* miRge.pl:97 */
+#define MIRGE_N_LIBS       4
+#define MIRGE_MAX_ROUNDS   8
+
+typedef struct mirge_ctx mirge_ctx;
+
+/* One cascade round = one bowtie command line of miRge.pl:333-339 plus its
+ * length filter (miRge.pl:326, 383-393). */
+typedef struct {
+    int32_t lib;      /* MIRGE_LIB_*                                               */
+    int32_t len_lt;   /* eligible iff length <  len_lt (0 = no test)               */
+    int32_t len_gt;   /* eligible iff length >  len_gt (0 = no test)               */
+    int32_t trim5;    /* bowtie -5                                                 */
+    int32_t trim3;    /* bowtie -3                                                 */
+    int32_t seedlen;  /* bowtie -l                                                 */
+    int32_t seedmm;   /* bowtie -n                                                 */
+    int32_t maxmm;    /* floor(bowtie -e / 30): FASTA reads cost 30 per mismatch   */
+} mirge_round;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+/* Opens a context on HIP device `device`.  species_dir = miRge.seqLibs/<species>
+ * (miRge.pl:92): the four libraries are read from <species_dir>/{mirna,hairpin,
+ * other,mrna}.fa (FASTA beside the .ebwt files; an .ebwt reader is future work)
+ * and their k-mer seed indexes are built on the device -- the step the
+ * reference pays as a bowtie process start + index load in every round
+ * (miRge.pl:353).  species_dir may be NULL: load libraries with
+ * mirge_load_library_* before mirge_annotate().  The cascade defaults to
+ * miRge's five rounds.  Returns NULL on failure (mirge_last_error(NULL)). */
+mirge_ctx*  mirge_open(const char* species_dir, int32_t n_samples, int32_t device);
+void        mirge_close(mirge_ctx*);
+const char* mirge_last_error(const mirge_ctx*);       /* ctx may be NULL */
+/* Forgets all reads/uniques/annotations but keeps libraries, indexes and every
+ * device buffer (no allocation on the next run of the same size). */
+int32_t     mirge_reset(mirge_ctx*, int32_t n_samples);
+
+/* ---- libraries (replaces the per-round index load inside bowtie, and
+ *      `bowtie-inspect -n`, miRge.pl:457-463) ------------------------------ */
+int32_t     mirge_load_library_fasta(mirge_ctx*, int32_t lib, const char* fasta_path);
+/* names: n NUL-terminated header lines back to back; seqs: concatenated ASCII; offs[n+1]. */
+int32_t     mirge_load_library_mem(mirge_ctx*, int32_t lib, int32_t n, const char* names,
+                                   const char* seqs, const uint64_t* offs);
+int32_t     mirge_lib_size(const mirge_ctx*, int32_t lib);                       /* number of references, <0 on error */
+const char* mirge_lib_name(const mirge_ctx*, int32_t lib, int32_t idx);          /* whole header line: bowtie-inspect -n */
+const char* mirge_lib_short_name(const mirge_ctx*, int32_t lib, int32_t idx);    /* up to first whitespace: bowtie's
+                                                                                    output column 3, miRge.pl:429      */
+/* Overrides the cascade (default: the five rounds of miRge.pl:326, 333-339). */
+int32_t     mirge_set_rounds(mirge_ctx*, int32_t n_rounds, const mirge_round* rounds);
+
+/* ---- collapse (replaces quantReads, miRge.pl:291-319) --------------------
+ * One call per sample, as the reference does; all samples share one table of
+ * unique sequences (miRge.pl:99-101). */
+int32_t     mirge_collapse_fastq(mirge_ctx*, const char* trimmed_fastq, int32_t sample, uint64_t* n_reads);
+/* Reads from host memory: concatenated ASCII + offs[n+1]. */
+int32_t     mirge_collapse_seqs(mirge_ctx*, const char* seqs, const uint64_t* offs, uint64_t n, int32_t sample);
+/* Reads already resident in HBM as a fixed-width ASCII matrix d_seqs[n][width]
+ * (zero padded, width a multiple of 16) + d_lens[n]: 2-bit packing and collapse
+ * both run on the device. */
+int32_t     mirge_collapse_ascii_dev(mirge_ctx*, const void* d_seqs, uint32_t width, const void* d_lens,
+                                     uint64_t n, int32_t sample);
+/* 2-bit packing alone (device to device).  d_keys16 receives the n16 reads that
+ * fit a 16-byte key (<= 56 nt, ACGT only), d_keys48 the n48 others (<= 124 nt
+ * or holding N); both must have room for n keys.  Order inside each stream is
+ * unspecified. */
+int32_t     mirge_pack_dev(mirge_ctx*, const void* d_seqs, uint32_t width, const void* d_lens, uint64_t n,
+                           void* d_keys16, uint64_t* n16, void* d_keys48, uint64_t* n48);
+/* Collapse of device-resident packed keys (the configuration bench.py times). */
+int32_t     mirge_collapse_packed_dev(mirge_ctx*, const void* d_keys16, uint64_t n16,
+                                      const void* d_keys48, uint64_t n48, int32_t sample);
+
+/* ---- cascade (replaces the loop of miRge.pl:346-371: writeSeqToAnnot,
+ *      system(bowtie), parseBowtieLog, parseAlignment, updateAnnotHash) ----- */
+int32_t     mirge_annotate(mirge_ctx*);
+/* annotStats of miRge.pl:352-354, 410-413; round is 1-based. */
+int32_t     mirge_round_stats(const mirge_ctx*, int32_t round, uint64_t* processed, uint64_t* aligned, double* seconds);
+
+/* ---- count vectors (replaces summarize, miRge.pl:453-494) ----------------
+ * quant, iscan: M x S row-major (M = mirge_lib_size(MIRGE_LIB_MIRNA), row =
+ * reference index); category: 5 x S (mirnaReads, hairpinReads, ornaReads,
+ * mrnaReads, remReads); len_hist: (MIRGE_MAX_READ_LEN+1) x S (readLengthHash,
+ * miRge.pl:315); trimmed_uniq: S (miRge.pl:468).  Any pointer may be NULL. */
+int32_t     mirge_counts(mirge_ctx*, const uint64_t** quant, const uint64_t** iscan, const uint64_t** category,
+                         const uint64_t** len_hist, const uint64_t** trimmed_uniq);
+/* Multi-GPU: the count vectors of this context as one flat uint64 buffer
+ * [quant | iscan | category | len_hist | trimmed_uniq], for a single sum
+ * all-reduce across ranks, and the setter that installs the reduced result. */
+uint64_t    mirge_counts_flat_len(const mirge_ctx*);
+int32_t     mirge_counts_flat_get(mirge_ctx*, uint64_t* out);
+int32_t     mirge_counts_flat_set(mirge_ctx*, const uint64_t* in);
+
+/* ---- per-unique results (feeds mapped.csv / unmapped.csv, miRge.pl:702-752,
+ *      845-863) -------------------------------------------------------------- */
+uint64_t    mirge_n_unique(const mirge_ctx*);
+/* ref_idx[r] = reference index in round r+1's library, or -1 (at most one round
+ * is set: a unique annotated in round r is never offered to later rounds,
+ * miRge.pl:382, 445).  ambiguous: bit r set iff round r+1's best stratum held
+ * more than one reference.  counts: S entries (0 = undefined in the reference). */
+int32_t     mirge_unique(mirge_ctx*, uint64_t i, const char** seq, int32_t ref_idx[MIRGE_MAX_ROUNDS],
+                         uint8_t* ambiguous, const uint32_t** counts);
+/* Bulk form: seqs[U][stride] zero padded; any pointer may be NULL. */
+int32_t     mirge_export_uniques(mirge_ctx*, char* seqs, uint32_t stride, uint8_t* lens, int8_t* ann_round,
+                                 int32_t* ann_ref, uint8_t* ann_amb);
+/* Sparse unique x sample counts as triplets. */
+uint64_t    mirge_n_counts(const mirge_ctx*);
+int32_t     mirge_export_counts(mirge_ctx*, uint64_t* uid, uint32_t* sample, uint32_t* count);
+
+/* ---- timing -------------------------------------------------------------- */
+/* Device time (HIP events on the library's stream) spent in the last
+ * mirge_collapse_* call / the last mirge_annotate() + count-vector pass, ms. */
+int32_t     mirge_last_timing(const mirge_ctx*, double* collapse_ms, double* annotate_ms, double* counts_ms);
+/* Named per-kernel device times of the last calls: fills up to cap entries,
+ * returns how many exist.  names[i] points at a static string. */
+int32_t     mirge_kernel_times(const mirge_ctx*, const char** names, double* ms, uint64_t* bytes_alg, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,240 @@
+"""ctypes binding of libmirge_hip.so (include/mirge_hip.h).
+
+There is no fallback: if the library is missing or no HIP device is usable, loading/opening
+raises.  Pointers handed to the *_dev entry points are raw device addresses (e.g.
+`torch.Tensor.data_ptr()`); torch is plumbing for memory and torch.distributed only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmirge_hip.so")
+
+LIB_MIRNA, LIB_HAIRPIN, LIB_OTHER, LIB_MRNA = 0, 1, 2, 3
+MAX_ROUNDS = 8
+MAX_READ_LEN = 124
+
+EXPORTS = [
+    "mirge_open", "mirge_close", "mirge_last_error", "mirge_reset", "mirge_load_library_fasta",
+    "mirge_load_library_mem", "mirge_lib_size", "mirge_lib_name", "mirge_lib_short_name", "mirge_set_rounds",
+    "mirge_collapse_fastq", "mirge_collapse_seqs", "mirge_collapse_ascii_dev", "mirge_pack_dev",
+    "mirge_collapse_packed_dev", "mirge_annotate", "mirge_round_stats", "mirge_counts", "mirge_counts_flat_len",
+    "mirge_counts_flat_get", "mirge_counts_flat_set", "mirge_n_unique", "mirge_unique", "mirge_export_uniques",
+    "mirge_n_counts", "mirge_export_counts", "mirge_last_timing", "mirge_kernel_times",
+]
+
+
+class MirgeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmirge_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Round(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("lib", "len_lt", "len_gt", "trim5", "trim3", "seedlen", "seedmm", "maxmm")]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
+    L.mirge_open.restype = vp; L.mirge_open.argtypes = [C.c_char_p, i32, i32]
+    L.mirge_close.restype = None; L.mirge_close.argtypes = [vp]
+    L.mirge_last_error.restype = C.c_char_p; L.mirge_last_error.argtypes = [vp]
+    L.mirge_reset.argtypes = [vp, i32]
+    L.mirge_load_library_fasta.argtypes = [vp, i32, C.c_char_p]
+    L.mirge_load_library_mem.argtypes = [vp, i32, i32, C.c_char_p, vp, vp]
+    L.mirge_lib_size.argtypes = [vp, i32]
+    L.mirge_lib_name.restype = C.c_char_p; L.mirge_lib_name.argtypes = [vp, i32, i32]
+    L.mirge_lib_short_name.restype = C.c_char_p; L.mirge_lib_short_name.argtypes = [vp, i32, i32]
+    L.mirge_set_rounds.argtypes = [vp, i32, vp]
+    L.mirge_collapse_fastq.argtypes = [vp, C.c_char_p, i32, C.POINTER(u64)]
+    L.mirge_collapse_seqs.argtypes = [vp, vp, vp, u64, i32]
+    L.mirge_collapse_ascii_dev.argtypes = [vp, vp, u32, vp, u64, i32]
+    L.mirge_pack_dev.argtypes = [vp, vp, u32, vp, u64, vp, C.POINTER(u64), vp, C.POINTER(u64)]
+    L.mirge_collapse_packed_dev.argtypes = [vp, vp, u64, vp, u64, i32]
+    L.mirge_annotate.argtypes = [vp]
+    L.mirge_round_stats.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
+    L.mirge_counts.argtypes = [vp] + [C.POINTER(C.POINTER(u64))] * 5
+    L.mirge_counts_flat_len.restype = u64; L.mirge_counts_flat_len.argtypes = [vp]
+    L.mirge_counts_flat_get.argtypes = [vp, vp]
+    L.mirge_counts_flat_set.argtypes = [vp, vp]
+    L.mirge_n_unique.restype = u64; L.mirge_n_unique.argtypes = [vp]
+    L.mirge_unique.argtypes = [vp, u64, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(C.c_uint8), C.POINTER(C.POINTER(u32))]
+    L.mirge_export_uniques.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+    L.mirge_n_counts.restype = u64; L.mirge_n_counts.argtypes = [vp]
+    L.mirge_export_counts.argtypes = [vp, vp, vp, vp]
+    L.mirge_last_timing.argtypes = [vp] + [C.POINTER(C.c_double)] * 3
+    L.mirge_kernel_times.argtypes = [vp, vp, vp, vp, i32]
+    _lib = L
+    return L
+
+
+class Context:
+    """One mirge_ctx.  Thin: every method is one C-ABI call plus numpy marshalling."""
+
+    def __init__(self, species_dir=None, n_samples=1, device=0):
+        self.L = load()
+        self.S = n_samples
+        self.h = self.L.mirge_open(species_dir.encode() if species_dir else None, n_samples, device)
+        if not self.h:
+            raise MirgeError(-3, self.L.mirge_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mirge_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise MirgeError(rc, self.L.mirge_last_error(self.h).decode())
+        return rc
+
+    # ---- libraries
+    def load_library(self, lib, names, text=None, offs=None, seqs=None):
+        """names: list[str]; either (text uint8, offs int64[n+1]) or seqs list[str]."""
+        if seqs is not None:
+            text = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+            offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+            np.cumsum([len(s) for s in seqs], out=offs[1:])
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        blob = ("\0".join(names) + "\0").encode()
+        self._chk(self.L.mirge_load_library_mem(self.h, lib, len(names), blob, text.ctypes.data, offs.ctypes.data))
+
+    def load_library_fasta(self, lib, path):
+        self._chk(self.L.mirge_load_library_fasta(self.h, lib, path.encode()))
+
+    def lib_size(self, lib):
+        return self._chk(self.L.mirge_lib_size(self.h, lib))
+
+    def lib_names(self, lib, short=False):
+        f = self.L.mirge_lib_short_name if short else self.L.mirge_lib_name
+        return [f(self.h, lib, i).decode() for i in range(self.lib_size(lib))]
+
+    def set_rounds(self, rounds):
+        arr = (Round * len(rounds))(*[Round(*r) for r in rounds])
+        self._chk(self.L.mirge_set_rounds(self.h, len(rounds), arr))
+
+    def reset(self, n_samples=None):
+        if n_samples is not None:
+            self.S = n_samples
+        self._chk(self.L.mirge_reset(self.h, self.S))
+
+    # ---- collapse
+    def collapse_fastq(self, path, sample):
+        n = C.c_uint64(0)
+        self._chk(self.L.mirge_collapse_fastq(self.h, path.encode(), sample, C.byref(n)))
+        return n.value
+
+    def collapse_seqs(self, reads, sample, lens=None):
+        """reads: list[str], or (uint8[n, W] matrix with lens)."""
+        if lens is not None:
+            lens = np.asarray(lens, dtype=np.int64)
+            mask = np.arange(reads.shape[1])[None, :] < lens[:, None]
+            text = np.ascontiguousarray(reads[mask])
+        else:
+            text = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+            lens = np.array([len(r) for r in reads], dtype=np.int64)
+        offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=offs[1:])
+        if len(text) == 0:
+            text = np.zeros(1, dtype=np.uint8)
+        self._chk(self.L.mirge_collapse_seqs(self.h, text.ctypes.data, offs.ctypes.data, len(lens), sample))
+
+    def collapse_ascii_dev(self, d_seqs, width, d_lens, n, sample):
+        self._chk(self.L.mirge_collapse_ascii_dev(self.h, d_seqs, width, d_lens, n, sample))
+
+    def pack_dev(self, d_seqs, width, d_lens, n, d_keys16, d_keys48):
+        n16 = C.c_uint64(0); n48 = C.c_uint64(0)
+        self._chk(self.L.mirge_pack_dev(self.h, d_seqs, width, d_lens, n, d_keys16, C.byref(n16), d_keys48, C.byref(n48)))
+        return n16.value, n48.value
+
+    def collapse_packed_dev(self, d_keys16, n16, d_keys48, n48, sample):
+        self._chk(self.L.mirge_collapse_packed_dev(self.h, d_keys16, n16, d_keys48, n48, sample))
+
+    # ---- cascade + counts
+    def annotate(self):
+        self._chk(self.L.mirge_annotate(self.h))
+
+    def round_stats(self, rnd):
+        p = C.c_uint64(); a = C.c_uint64(); s = C.c_double()
+        self._chk(self.L.mirge_round_stats(self.h, rnd, C.byref(p), C.byref(a), C.byref(s)))
+        return p.value, a.value, s.value
+
+    def counts(self):
+        ptrs = [C.POINTER(C.c_uint64)() for _ in range(5)]
+        self._chk(self.L.mirge_counts(self.h, *[C.byref(p) for p in ptrs]))
+        M, S = self.lib_size(LIB_MIRNA), self.S
+        shp = [(M, S), (M, S), (5, S), (MAX_READ_LEN + 1, S), (S,)]
+        out = []
+        for p, sh in zip(ptrs, shp):
+            n = int(np.prod(sh))
+            out.append(np.ctypeslib.as_array(p, shape=(max(n, 1),))[:n].reshape(sh).copy())
+        return dict(quant=out[0], iscan=out[1], cat=out[2], lenhist=out[3], tuniq=out[4])
+
+    def counts_flat(self):
+        n = self.L.mirge_counts_flat_len(self.h)
+        buf = np.zeros(n, dtype=np.uint64)
+        self._chk(self.L.mirge_counts_flat_get(self.h, buf.ctypes.data))
+        return buf
+
+    def set_counts_flat(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint64)
+        assert len(buf) == self.L.mirge_counts_flat_len(self.h)
+        self._chk(self.L.mirge_counts_flat_set(self.h, buf.ctypes.data))
+
+    # ---- per-unique results
+    def n_unique(self):
+        return self.L.mirge_n_unique(self.h)
+
+    def export_uniques(self):
+        U = self.n_unique()
+        stride = 128
+        seqs = np.zeros((max(U, 1), stride), dtype=np.uint8)
+        lens = np.zeros(max(U, 1), dtype=np.uint8)
+        rnd = np.zeros(max(U, 1), dtype=np.int8); ref = np.zeros(max(U, 1), dtype=np.int32); amb = np.zeros(max(U, 1), dtype=np.uint8)
+        self._chk(self.L.mirge_export_uniques(self.h, seqs.ctypes.data, stride, lens.ctypes.data, rnd.ctypes.data,
+                                              ref.ctypes.data, amb.ctypes.data))
+        return seqs[:U], lens[:U], rnd[:U], ref[:U], amb[:U]
+
+    def export_counts(self):
+        n = self.L.mirge_n_counts(self.h)
+        uid = np.zeros(max(n, 1), dtype=np.uint64); smp = np.zeros(max(n, 1), dtype=np.uint32); cnt = np.zeros(max(n, 1), dtype=np.uint32)
+        self._chk(self.L.mirge_export_counts(self.h, uid.ctypes.data, smp.ctypes.data, cnt.ctypes.data))
+        return uid[:n], smp[:n], cnt[:n]
+
+    def unique(self, i):
+        seq = C.c_char_p(); refs = (C.c_int32 * MAX_ROUNDS)(); amb = C.c_uint8(); cnt = C.POINTER(C.c_uint32)()
+        self._chk(self.L.mirge_unique(self.h, i, C.byref(seq), refs, C.byref(amb), C.byref(cnt)))
+        return seq.value.decode(), list(refs), amb.value, [cnt[s] for s in range(self.S)]
+
+    # ---- timing
+    def last_timing(self):
+        a = C.c_double(); b = C.c_double(); c = C.c_double()
+        self._chk(self.L.mirge_last_timing(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(collapse_ms=a.value, annotate_ms=b.value, counts_ms=c.value)
+
+    def kernel_times(self):
+        cap = 64
+        names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); by = (C.c_uint64 * cap)()
+        n = self._chk(self.L.mirge_kernel_times(self.h, names, ms, by, cap))
+        return {names[i].decode(): (ms[i], by[i]) for i in range(min(n, cap))}

@@ -1,0 +1,841 @@
+// mirge_hip.hip -- host side of libmirge_hip.so: context, library loading + seed-index build,
+// orchestration of the collapse / cascade / count-vector kernels, and the C ABI declared in
+// include/mirge_hip.h.  There is no CPU implementation of the path in here: every entry point
+// that computes launches the kernels of kernels.h and fails if HIP does.
+#include "../../include/mirge_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mg;
+
+namespace {
+
+thread_local std::string g_open_error;
+
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes, bool keep, size_t keep_bytes, hipStream_t st) {
+        if (bytes <= cap) return hipSuccess;
+        size_t ncap = std::max(bytes, cap + cap / 2);
+        ncap = (ncap + 255) & ~size_t(255);
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, ncap);
+        if (e != hipSuccess) return e;
+        if (keep && p && keep_bytes) {
+            e = hipMemcpyAsync(q, p, std::min(keep_bytes, cap), hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) { (void)hipFree(q); return e; }
+            e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { (void)hipFree(q); return e; }
+        }
+        if (p) (void)hipFree(p);
+        p = q; cap = ncap;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Lib {
+    bool loaded = false;
+    std::vector<std::string> names, short_names;
+    std::vector<uint32_t> ref_start;     // n + 1
+    uint64_t T = 0;
+    int kb = 0;
+    DevBuf text, bad, koff, kpos, dref;
+    LibDev dev() const {
+        LibDev L;
+        L.text = text.as<uint64_t>(); L.bad = bad.as<uint64_t>(); L.koff = koff.as<uint32_t>();
+        L.kpos = kpos.as<uint32_t>(); L.ref_start = dref.as<uint32_t>();
+        L.n_refs = (uint32_t)names.size(); L.T = (uint32_t)T; L.kb = kb;
+        return L;
+    }
+    void release() { text.release(); bad.release(); koff.release(); kpos.release(); dref.release(); loaded = false; }
+};
+
+struct Segment { int sample; uint64_t start, count; };
+
+// The unique table of one key class (16-byte or 48-byte keys).
+struct Class {
+    int KW = 2;
+    uint64_t U = 0;             // uniques so far (all samples)
+    uint64_t coo_n = 0;         // (unique, count) entries so far
+    DevBuf ukeys, coo_g, coo_c;
+    DevBuf gslots; uint64_t gcap = 0; bool gvalid = false;     // cross-sample table, built lazily
+    DevBuf ann_round, ann_ref, ann_amb;
+    std::vector<Segment> segs;
+    void reset() { U = 0; coo_n = 0; gvalid = false; segs.clear(); }
+    void release() { ukeys.release(); coo_g.release(); coo_c.release(); gslots.release(); ann_round.release(); ann_ref.release(); ann_amb.release(); }
+};
+
+struct KTime { const char* name; hipEvent_t a = nullptr, b = nullptr; bool used = false; double ms = 0; uint64_t bytes = 0; };
+
+}  // namespace
+
+struct mirge_ctx {
+    int device = 0;
+    int S = 1;
+    hipStream_t st = nullptr;
+    std::string err;
+    Lib libs[MIRGE_N_LIBS];
+    int n_rounds = 5;
+    mirge_round rounds[MIRGE_MAX_ROUNDS];
+    Class cls[2];                                   // [0] 16-byte keys, [1] 48-byte keys
+    // workspaces
+    DevBuf lslots, cnt, rep, ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist;
+    DevBuf d_stats, d_quant, d_iscan, d_cat, d_len, d_tu;
+    unsigned long long* h_ctr = nullptr;            // pinned, 16 words
+    // results
+    bool annotated = false, counts_valid = false, host_valid = false;
+    uint64_t stats[MIRGE_MAX_ROUNDS][2] = {};
+    double round_ms[MIRGE_MAX_ROUNDS] = {};
+    std::vector<uint64_t> h_quant, h_iscan, h_cat, h_len, h_tu;
+    // host copies for per-unique export
+    std::vector<uint64_t> h_keys[2];
+    std::vector<uint8_t> h_round[2], h_amb[2];
+    std::vector<int32_t> h_ref[2];
+    std::vector<uint32_t> h_coo_g[2], h_coo_c[2];
+    std::vector<uint64_t> csr_off; std::vector<uint32_t> csr_sample, csr_count;
+    std::string uniq_seq; std::vector<uint32_t> uniq_counts;
+    // timing
+    std::vector<KTime> kt;
+    double collapse_ms = 0, annotate_ms = 0, counts_ms = 0;
+};
+
+namespace {
+
+int fail(mirge_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_open_error = msg;
+    return code;
+}
+#define HIPCHK(c, call)                                                                         \
+    do { hipError_t e__ = (call);                                                               \
+         if (e__ != hipSuccess) return fail((c), MIRGE_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); } while (0)
+
+KTime& ktime(mirge_ctx* c, const char* name) {
+    for (auto& k : c->kt) if (k.name == name || !strcmp(k.name, name)) return k;
+    KTime k; k.name = name;
+    (void)hipEventCreate(&k.a); (void)hipEventCreate(&k.b);
+    c->kt.push_back(k);
+    return c->kt.back();
+}
+void kt_begin(mirge_ctx* c, const char* name) { KTime& k = ktime(c, name); (void)hipEventRecord(k.a, c->st); }
+void kt_end(mirge_ctx* c, const char* name, uint64_t bytes) { KTime& k = ktime(c, name); (void)hipEventRecord(k.b, c->st); k.used = true; k.bytes = bytes; k.ms = -1; }
+void kt_resolve(mirge_ctx* c) {
+    for (auto& k : c->kt) if (k.used && k.ms < 0) { float ms = 0; if (hipEventElapsedTime(&ms, k.a, k.b) == hipSuccess) k.ms = ms; else k.ms = 0; }
+}
+void kt_clear(mirge_ctx* c, const char* prefix) {
+    for (auto& k : c->kt) if (!strncmp(k.name, prefix, strlen(prefix))) { k.used = false; k.ms = 0; }
+}
+
+uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1024; while (p < x) p <<= 1; return p; }
+
+// ---- exclusive scan of n uint32 (in -> out), using c->scan_tmp
+int scan_exclusive(mirge_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
+    uint32_t m = (uint32_t)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    HIPCHK(c, c->scan_tmp.ensure((size_t)m * 4 + 16, false, 0, c->st));
+    hipLaunchKernelGGL(k_scan_sums, dim3(m), dim3(256), 0, c->st, in, n, c->scan_tmp.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->st, c->scan_tmp.as<uint32_t>(), m);
+    hipLaunchKernelGGL(k_scan_apply, dim3(m), dim3(256), 0, c->st, in, n, c->scan_tmp.as<uint32_t>(), out);
+    HIPCHK(c, hipGetLastError());
+    return MIRGE_OK;
+}
+
+// ---- library: host packing + device index build
+int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const char* seqs, const uint64_t* offs) {
+    if (lib < 0 || lib >= MIRGE_N_LIBS) return fail(c, MIRGE_E_ARG, "library index out of range");
+    Lib& L = c->libs[lib];
+    size_t n = names.size();
+    uint64_t T = 0;
+    for (size_t i = 0; i < n; ++i) T += (offs[i + 1] - offs[i]) + 1;
+    if (T >= (1ull << 31)) return fail(c, MIRGE_E_LIMIT, "library larger than 2^31 nt");
+    size_t words = (size_t)(T / 32) + 10, bwords = (size_t)(T / 64) + 10;
+    std::vector<uint64_t> text(words, 0), bad(bwords, 0);
+    L.ref_start.assign(n + 1, 0);
+    uint64_t p = 0;
+    for (size_t i = 0; i < n; ++i) {
+        L.ref_start[i] = (uint32_t)p;
+        for (uint64_t j = offs[i]; j < offs[i + 1]; ++j, ++p) {
+            uint8_t ch = (uint8_t)seqs[j];
+            if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32);
+            int code = base_code(ch);
+            if (code >= 0 && code < 4) text[p >> 5] |= (uint64_t)code << (2 * (p & 31));
+            else bad[p >> 6] |= 1ull << (p & 63);                 // reference N: not alignable
+        }
+        bad[p >> 6] |= 1ull << (p & 63);                           // separator
+        ++p;
+    }
+    L.ref_start[n] = (uint32_t)p;
+    L.T = T;
+    L.names = std::move(names);
+    L.short_names.clear();
+    for (auto& nm : L.names) { size_t e = nm.find_first_of(" \t"); L.short_names.push_back(e == std::string::npos ? nm : nm.substr(0, e)); }
+    int kb = (int)std::lround(std::log2((double)std::max<uint64_t>(T, 16)) / 2.0);
+    L.kb = std::min(14, std::max(4, kb));
+    const char* env = getenv("MIRGE_KB");
+    if (env && atoi(env) >= 2 && atoi(env) <= 15) L.kb = atoi(env);
+    uint64_t nb = 1ull << (2 * L.kb);
+    HIPCHK(c, L.text.ensure(words * 8, false, 0, c->st));
+    HIPCHK(c, L.bad.ensure(bwords * 8, false, 0, c->st));
+    HIPCHK(c, L.dref.ensure((n + 1) * 4, false, 0, c->st));
+    HIPCHK(c, L.koff.ensure((nb + 1) * 4, false, 0, c->st));
+    HIPCHK(c, L.kpos.ensure(std::max<uint64_t>(T, 1) * 4, false, 0, c->st));
+    HIPCHK(c, c->hist.ensure((nb + 1) * 4, false, 0, c->st));
+    HIPCHK(c, hipMemcpyAsync(L.text.p, text.data(), words * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(L.bad.p, bad.data(), bwords * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(L.dref.p, L.ref_start.data(), (n + 1) * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (nb + 1) * 4, c->st));
+    if (T > 0) {
+        uint32_t grid = (uint32_t)((T + 255) / 256);
+        hipLaunchKernelGGL(k_kmer_hist, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, c->hist.as<uint32_t>());
+        int rc = scan_exclusive(c, c->hist.as<uint32_t>(), L.koff.as<uint32_t>(), nb + 1);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->hist.p, L.koff.p, nb * 4, hipMemcpyDeviceToDevice, c->st));
+        hipLaunchKernelGGL(k_kmer_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, c->hist.as<uint32_t>(), L.kpos.as<uint32_t>());
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemsetAsync(L.koff.p, 0, (nb + 1) * 4, c->st));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    L.loaded = true;
+    c->annotated = false; c->counts_valid = false; c->host_valid = false;
+    return MIRGE_OK;
+}
+
+int read_file(mirge_ctx* c, const char* path, std::string& out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(c, MIRGE_E_IO, std::string("cannot open ") + path);
+    fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+    out.resize((size_t)std::max(0L, sz));
+    size_t got = sz > 0 ? fread(&out[0], 1, (size_t)sz, f) : 0;
+    fclose(f);
+    if ((long)got != sz) return fail(c, MIRGE_E_IO, std::string("short read on ") + path);
+    return MIRGE_OK;
+}
+
+int load_fasta(mirge_ctx* c, int lib, const char* path) {
+    std::string data;
+    int rc = read_file(c, path, data);
+    if (rc) return rc;
+    std::vector<std::string> names; std::string seqs; std::vector<uint64_t> offs;
+    size_t i = 0, n = data.size();
+    while (i < n) {
+        size_t e = data.find('\n', i); if (e == std::string::npos) e = n;
+        size_t le = e; while (le > i && (data[le - 1] == '\r')) --le;
+        if (le > i && data[i] == '>') { names.emplace_back(data, i + 1, le - i - 1); offs.push_back(seqs.size()); }
+        else if (!names.empty()) seqs.append(data, i, le - i);
+        else if (le > i) return fail(c, MIRGE_E_FORMAT, std::string(path) + ": sequence data before the first '>' header");
+        i = e + 1;
+    }
+    offs.push_back(seqs.size());
+    return load_library(c, lib, std::move(names), seqs.data(), offs.data());
+}
+
+// ---- collapse of one key class
+template <int KW>
+int collapse_class(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64, int sample, const char* tagA, const char* tagB) {
+    if (n64 >= 0xFFFFFFF0ull) return fail(c, MIRGE_E_LIMIT, "more than 2^32 reads in one collapse call");
+    if (C.U + n64 >= 0xFFFFFFF0ull) return fail(c, MIRGE_E_LIMIT, "more than 2^32 unique sequences");
+    uint32_t n = (uint32_t)n64;
+    if (n == 0) { C.segs.push_back({sample, C.coo_n, 0}); return MIRGE_OK; }
+    uint64_t capL = pow2_at_least(2ull * n);
+    HIPCHK(c, c->lslots.ensure(capL * 4, false, 0, c->st));
+    HIPCHK(c, c->cnt.ensure((size_t)n * 4, false, 0, c->st));
+    HIPCHK(c, c->ctr.ensure(64, false, 0, c->st));
+    HIPCHK(c, C.ukeys.ensure((C.U + n) * KW * 8, true, C.U * KW * 8, c->st));
+    HIPCHK(c, C.coo_g.ensure((C.coo_n + n) * 4, true, C.coo_n * 4, c->st));
+    HIPCHK(c, C.coo_c.ensure((C.coo_n + n) * 4, true, C.coo_n * 4, c->st));
+    bool use_g = C.U > 0;
+    if (use_g) {
+        uint64_t need = pow2_at_least(2ull * (C.U + n));
+        if (!C.gvalid || C.gcap < need) {
+            HIPCHK(c, C.gslots.ensure(need * 4, false, 0, c->st));
+            C.gcap = need;
+            HIPCHK(c, hipMemsetAsync(C.gslots.p, 0xFF, need * 4, c->st));
+            hipLaunchKernelGGL((k_gtable_insert<KW>), dim3((uint32_t)((C.U + 255) / 256)), dim3(256), 0, c->st,
+                               C.ukeys.as<uint64_t>(), 0u, (uint32_t)C.U, C.gslots.as<uint32_t>(), (uint32_t)(C.gcap - 1));
+            C.gvalid = true;
+        }
+    }
+    HIPCHK(c, hipMemsetAsync(c->lslots.p, 0xFF, capL * 4, c->st));
+    HIPCHK(c, hipMemsetAsync(c->cnt.p, 0, (size_t)n * 4, c->st));
+    HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 64, c->st));
+    constexpr int T = KW == 2 ? 2048 : 512;
+    kt_begin(c, tagA);
+    hipLaunchKernelGGL((k_collapse_local<KW, T, 256>), dim3((n + T - 1) / T), dim3(256), 0, c->st,
+                       d_keys, n, c->lslots.as<uint32_t>(), (uint32_t)(capL - 1), c->cnt.as<uint32_t>(), (uint32_t*)nullptr);
+    kt_end(c, tagA, (uint64_t)n * KW * 8);
+    kt_begin(c, tagB);
+    hipLaunchKernelGGL((k_collapse_emit<KW>), dim3((n + 255) / 256), dim3(256), 0, c->st,
+                       d_keys, c->cnt.as<uint32_t>(), n, use_g ? C.gslots.as<uint32_t>() : (const uint32_t*)nullptr,
+                       (uint32_t)(C.gcap ? C.gcap - 1 : 0), C.ukeys.as<uint64_t>(), (uint32_t)C.U,
+                       C.coo_g.as<uint32_t>() + C.coo_n, C.coo_c.as<uint32_t>() + C.coo_n,
+                       c->ctr.as<unsigned long long>(), (uint32_t*)nullptr);
+    kt_end(c, tagB, 0);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 16, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    uint64_t n_new = c->h_ctr[0], n_emit = c->h_ctr[1];
+    ktime(c, tagB).bytes = n_new * (KW * 8 + 4) + n_emit * 4;
+    if (C.gvalid && n_new) {
+        hipLaunchKernelGGL((k_gtable_insert<KW>), dim3((uint32_t)((n_new + 255) / 256)), dim3(256), 0, c->st,
+                           C.ukeys.as<uint64_t>(), (uint32_t)C.U, (uint32_t)(C.U + n_new), C.gslots.as<uint32_t>(), (uint32_t)(C.gcap - 1));
+        HIPCHK(c, hipGetLastError());
+    }
+    C.segs.push_back({sample, C.coo_n, n_emit});
+    C.U += n_new; C.coo_n += n_emit;
+    return MIRGE_OK;
+}
+
+int collapse_packed(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, uint64_t n48, int sample) {
+    if (sample < 0 || sample >= c->S) return fail(c, MIRGE_E_ARG, "sample index out of range");
+    c->annotated = false; c->counts_valid = false; c->host_valid = false;
+    kt_clear(c, "collapse");
+    hipEvent_t a, b;
+    HIPCHK(c, hipEventCreate(&a)); HIPCHK(c, hipEventCreate(&b));
+    HIPCHK(c, hipEventRecord(a, c->st));
+    int rc = collapse_class<2>(c, c->cls[0], (const uint64_t*)d16, n16, sample, "collapse_local16", "collapse_emit16");
+    if (!rc) rc = collapse_class<6>(c, c->cls[1], (const uint64_t*)d48, n48, sample, "collapse_local48", "collapse_emit48");
+    if (!rc) {
+        HIPCHK(c, hipEventRecord(b, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        float ms = 0; (void)hipEventElapsedTime(&ms, a, b); c->collapse_ms = ms;
+        kt_resolve(c);
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return rc;
+}
+
+// pack a device-resident ASCII matrix into the two key streams at out16/out48 (appending at the
+// positions held in c->ctr[0..1]); reports kernel-detected input errors.
+int pack_launch(mirge_ctx* c, const void* d_seqs, uint32_t width, const void* d_lens, uint64_t n, void* out16, void* out48) {
+    if (width == 0 || width % 16) return fail(c, MIRGE_E_ARG, "matrix width must be a positive multiple of 16");
+    if (n == 0) return MIRGE_OK;
+    kt_begin(c, "pack");
+    hipLaunchKernelGGL(k_pack, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->st, (const uint8_t*)d_seqs, width,
+                       (const uint8_t*)d_lens, n, (uint64_t*)out16, (uint64_t*)out48, c->ctr.as<unsigned long long>());
+    kt_end(c, "pack", n * 16);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 32, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (c->h_ctr[2] == 4) return fail(c, MIRGE_E_FORMAT, "read " + std::to_string(c->h_ctr[3]) + " holds a character other than A, C, G, T, N");
+    if (c->h_ctr[2] == 5) return fail(c, MIRGE_E_LIMIT, "read " + std::to_string(c->h_ctr[3]) + " is longer than " + std::to_string(MIRGE_MAX_READ_LEN) + " nt");
+    return MIRGE_OK;
+}
+
+// host reads (concatenated + offsets) -> chunks of ASCII matrix -> device pack -> collapse
+int collapse_host(mirge_ctx* c, const char* seqs, const uint64_t* offs, uint64_t n, int sample) {
+    if (sample < 0 || sample >= c->S) return fail(c, MIRGE_E_ARG, "sample index out of range");
+    uint64_t maxlen = 0;
+    for (uint64_t i = 0; i < n; ++i) maxlen = std::max(maxlen, offs[i + 1] - offs[i]);
+    if (maxlen > MIRGE_MAX_READ_LEN) return fail(c, MIRGE_E_LIMIT, "a read is longer than " + std::to_string(MIRGE_MAX_READ_LEN) + " nt");
+    uint32_t W = (uint32_t)std::max<uint64_t>(16, (maxlen + 15) / 16 * 16);
+    const uint64_t CH = 1u << 22;
+    HIPCHK(c, c->ctr.ensure(64, false, 0, c->st));
+    HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 64, c->st));
+    HIPCHK(c, c->stage16.ensure(std::max<uint64_t>(n, 1) * 16, false, 0, c->st));
+    std::vector<uint8_t> mat, lens;
+    uint64_t n48 = 0;
+    for (uint64_t b = 0; b < n; b += CH) {
+        uint64_t m = std::min(CH, n - b);
+        mat.assign((size_t)m * W, 0); lens.resize((size_t)m);
+        for (uint64_t i = 0; i < m; ++i) {
+            uint64_t l = offs[b + i + 1] - offs[b + i];
+            memcpy(&mat[(size_t)i * W], seqs + offs[b + i], (size_t)l);
+            lens[(size_t)i] = (uint8_t)l;
+        }
+        HIPCHK(c, c->in_seqs.ensure((size_t)m * W, false, 0, c->st));
+        HIPCHK(c, c->in_lens.ensure((size_t)m, false, 0, c->st));
+        HIPCHK(c, c->stage48.ensure((n48 + m) * 48, true, n48 * 48, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->in_seqs.p, mat.data(), (size_t)m * W, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->in_lens.p, lens.data(), (size_t)m, hipMemcpyHostToDevice, c->st));
+        int rc = pack_launch(c, c->in_seqs.p, W, c->in_lens.p, m, c->stage16.p, c->stage48.p);
+        if (rc) return rc;
+        n48 = c->h_ctr[1];
+    }
+    uint64_t n16 = n ? c->h_ctr[0] : 0;
+    return collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
+}
+
+// ---- cascade + count vectors
+template <int KW>
+int annotate_class(mirge_ctx* c, Class& C, int r, const mirge_round& R) {
+    if (C.U == 0) return MIRGE_OK;
+    RoundDev P{R.lib, R.len_lt, R.len_gt, R.trim5, R.trim3, R.seedlen, R.seedmm, R.maxmm};
+    hipLaunchKernelGGL((k_match_round<KW>), dim3((uint32_t)((C.U + 255) / 256)), dim3(256), 0, c->st,
+                       C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
+                       C.ann_amb.as<uint8_t>(), c->libs[R.lib].dev(), P, r + 1, c->d_stats.as<unsigned long long>() + 2 * r);
+    HIPCHK(c, hipGetLastError());
+    return MIRGE_OK;
+}
+
+template <int KW>
+int counts_class(mirge_ctx* c, Class& C, int M) {
+    for (auto& sg : C.segs) {
+        if (!sg.count) continue;
+        uint32_t grid = (uint32_t)std::min<uint64_t>(512, (sg.count + 255) / 256);
+        hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(256), 0, c->st, C.coo_g.as<uint32_t>() + sg.start,
+                           C.coo_c.as<uint32_t>() + sg.start, (uint32_t)sg.count, sg.sample, c->S, C.ukeys.as<uint64_t>(),
+                           C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), M, 1, 5,
+                           c->d_quant.as<unsigned long long>(), c->d_iscan.as<unsigned long long>(),
+                           c->d_cat.as<unsigned long long>(), c->d_len.as<unsigned long long>(), c->d_tu.as<unsigned long long>());
+    }
+    HIPCHK(c, hipGetLastError());
+    return MIRGE_OK;
+}
+
+static const char* kRoundNames[MIRGE_MAX_ROUNDS] = {"match_round1", "match_round2", "match_round3", "match_round4",
+                                                    "match_round5", "match_round6", "match_round7", "match_round8"};
+
+int annotate(mirge_ctx* c) {
+    for (int r = 0; r < c->n_rounds; ++r) {
+        int lib = c->rounds[r].lib;
+        if (lib < 0 || lib >= MIRGE_N_LIBS || !c->libs[lib].loaded)
+            return fail(c, MIRGE_E_ARG, "round " + std::to_string(r + 1) + " uses a library that is not loaded");
+    }
+    if (!c->libs[MIRGE_LIB_MIRNA].loaded) return fail(c, MIRGE_E_ARG, "mirna library not loaded");
+    kt_clear(c, "match"); kt_clear(c, "counts");
+    for (int k = 0; k < 2; ++k) {
+        Class& C = c->cls[k];
+        size_t U = std::max<uint64_t>(C.U, 1);
+        HIPCHK(c, C.ann_round.ensure(U, false, 0, c->st));
+        HIPCHK(c, C.ann_ref.ensure(U * 4, false, 0, c->st));
+        HIPCHK(c, C.ann_amb.ensure(U, false, 0, c->st));
+        HIPCHK(c, hipMemsetAsync(C.ann_round.p, 0, U, c->st));
+        HIPCHK(c, hipMemsetAsync(C.ann_ref.p, 0xFF, U * 4, c->st));
+        HIPCHK(c, hipMemsetAsync(C.ann_amb.p, 0, U, c->st));
+    }
+    int M = (int)c->libs[MIRGE_LIB_MIRNA].names.size(), S = c->S;
+    size_t qn = std::max<size_t>((size_t)M * S, 1);
+    HIPCHK(c, c->d_stats.ensure(MIRGE_MAX_ROUNDS * 16, false, 0, c->st));
+    HIPCHK(c, c->d_quant.ensure(qn * 8, false, 0, c->st));
+    HIPCHK(c, c->d_iscan.ensure(qn * 8, false, 0, c->st));
+    HIPCHK(c, c->d_cat.ensure((size_t)5 * S * 8, false, 0, c->st));
+    HIPCHK(c, c->d_len.ensure((size_t)128 * S * 8, false, 0, c->st));
+    HIPCHK(c, c->d_tu.ensure((size_t)S * 8, false, 0, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, MIRGE_MAX_ROUNDS * 16, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_quant.p, 0, qn * 8, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_iscan.p, 0, qn * 8, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_cat.p, 0, (size_t)5 * S * 8, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_len.p, 0, (size_t)128 * S * 8, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_tu.p, 0, (size_t)S * 8, c->st));
+    hipEvent_t e0, e1, e2;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
+    HIPCHK(c, hipEventRecord(e0, c->st));
+    for (int r = 0; r < c->n_rounds; ++r) {
+        kt_begin(c, kRoundNames[r]);
+        int rc = annotate_class<2>(c, c->cls[0], r, c->rounds[r]);
+        if (!rc) rc = annotate_class<6>(c, c->cls[1], r, c->rounds[r]);
+        if (rc) return rc;
+        kt_end(c, kRoundNames[r], 0);
+    }
+    HIPCHK(c, hipEventRecord(e1, c->st));
+    kt_begin(c, "counts");
+    int rc = counts_class<2>(c, c->cls[0], M);
+    if (!rc) rc = counts_class<6>(c, c->cls[1], M);
+    if (rc) return rc;
+    kt_end(c, "counts", (c->cls[0].coo_n + c->cls[1].coo_n) * 8 + (uint64_t)16 * M * S);
+    HIPCHK(c, hipEventRecord(e2, c->st));
+    c->h_quant.assign(qn, 0); c->h_iscan.assign(qn, 0); c->h_cat.assign((size_t)5 * S, 0);
+    c->h_len.assign((size_t)128 * S, 0); c->h_tu.assign((size_t)S, 0);
+    uint64_t hs[MIRGE_MAX_ROUNDS * 2];
+    HIPCHK(c, hipMemcpyAsync(hs, c->d_stats.p, sizeof hs, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->h_quant.data(), c->d_quant.p, (size_t)M * S * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->h_iscan.data(), c->d_iscan.p, (size_t)M * S * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->h_cat.data(), c->d_cat.p, (size_t)5 * S * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->h_len.data(), c->d_len.p, (size_t)128 * S * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->h_tu.data(), c->d_tu.p, (size_t)S * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1); c->annotate_ms = ms;
+    (void)hipEventElapsedTime(&ms, e1, e2); c->counts_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    kt_resolve(c);
+    for (int r = 0; r < c->n_rounds; ++r) {
+        c->stats[r][0] = hs[2 * r]; c->stats[r][1] = hs[2 * r + 1];
+        c->round_ms[r] = ktime(c, kRoundNames[r]).ms;
+        // algorithmic bytes of the round: 20 B per eligible unique + the 2-bit library once
+        ktime(c, kRoundNames[r]).bytes = 20 * hs[2 * r] + c->libs[c->rounds[r].lib].T / 4;
+    }
+    c->annotated = true; c->counts_valid = true; c->host_valid = false;
+    return MIRGE_OK;
+}
+
+// ---- host copies for the per-unique accessors
+void decode_key(const uint64_t* k, int KW, char* out, int* len_out) {
+    int SW = KW == 2 ? 2 : 4;
+    int len = (int)(k[SW - 1] >> 56);
+    for (int i = 0; i < len; ++i) {
+        int code = (int)((k[i >> 5] >> (2 * (i & 31))) & 3);
+        bool isN = KW == 6 && ((k[4 + (i >> 6)] >> (i & 63)) & 1);
+        out[i] = isN ? 'N' : "ACGT"[code];
+    }
+    *len_out = len;
+}
+
+int fetch_host(mirge_ctx* c) {
+    if (c->host_valid) return MIRGE_OK;
+    for (int k = 0; k < 2; ++k) {
+        Class& C = c->cls[k];
+        int KW = k == 0 ? 2 : 6;
+        c->h_keys[k].assign((size_t)C.U * KW, 0);
+        c->h_round[k].assign((size_t)C.U, 0); c->h_ref[k].assign((size_t)C.U, -1); c->h_amb[k].assign((size_t)C.U, 0);
+        c->h_coo_g[k].assign((size_t)C.coo_n, 0); c->h_coo_c[k].assign((size_t)C.coo_n, 0);
+        if (C.U) {
+            HIPCHK(c, hipMemcpyAsync(c->h_keys[k].data(), C.ukeys.p, (size_t)C.U * KW * 8, hipMemcpyDeviceToHost, c->st));
+            if (c->annotated) {
+                HIPCHK(c, hipMemcpyAsync(c->h_round[k].data(), C.ann_round.p, (size_t)C.U, hipMemcpyDeviceToHost, c->st));
+                HIPCHK(c, hipMemcpyAsync(c->h_ref[k].data(), C.ann_ref.p, (size_t)C.U * 4, hipMemcpyDeviceToHost, c->st));
+                HIPCHK(c, hipMemcpyAsync(c->h_amb[k].data(), C.ann_amb.p, (size_t)C.U, hipMemcpyDeviceToHost, c->st));
+            }
+        }
+        if (C.coo_n) {
+            HIPCHK(c, hipMemcpyAsync(c->h_coo_g[k].data(), C.coo_g.p, (size_t)C.coo_n * 4, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipMemcpyAsync(c->h_coo_c[k].data(), C.coo_c.p, (size_t)C.coo_n * 4, hipMemcpyDeviceToHost, c->st));
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    // CSR unique -> (sample, count)
+    uint64_t U0 = c->cls[0].U, U = U0 + c->cls[1].U;
+    c->csr_off.assign((size_t)U + 1, 0);
+    for (int k = 0; k < 2; ++k) for (auto g : c->h_coo_g[k]) c->csr_off[(size_t)(g + (k ? U0 : 0)) + 1]++;
+    for (uint64_t u = 0; u < U; ++u) c->csr_off[(size_t)u + 1] += c->csr_off[(size_t)u];
+    uint64_t tot = c->csr_off[(size_t)U];
+    c->csr_sample.assign((size_t)tot, 0); c->csr_count.assign((size_t)tot, 0);
+    std::vector<uint64_t> cur(c->csr_off.begin(), c->csr_off.end() - 1);
+    for (int k = 0; k < 2; ++k)
+        for (auto& sg : c->cls[k].segs)
+            for (uint64_t e = sg.start; e < sg.start + sg.count; ++e) {
+                uint64_t u = c->h_coo_g[k][(size_t)e] + (k ? U0 : 0);
+                uint64_t at = cur[(size_t)u]++;
+                c->csr_sample[(size_t)at] = (uint32_t)sg.sample; c->csr_count[(size_t)at] = c->h_coo_c[k][(size_t)e];
+            }
+    c->host_valid = true;
+    return MIRGE_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+
+extern "C" {
+
+const char* mirge_last_error(const mirge_ctx* c) { return c ? c->err.c_str() : g_open_error.c_str(); }
+
+mirge_ctx* mirge_open(const char* species_dir, int32_t n_samples, int32_t device) {
+    if (n_samples < 1) { fail(nullptr, MIRGE_E_ARG, "n_samples must be >= 1"); return nullptr; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        fail(nullptr, MIRGE_E_HIP, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                                       " (libmirge_hip has no CPU path)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { fail(nullptr, MIRGE_E_ARG, "device index out of range"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fail(nullptr, MIRGE_E_HIP, "hipSetDevice failed"); return nullptr; }
+    mirge_ctx* c = new mirge_ctx();
+    c->device = device; c->S = n_samples;
+    c->cls[0].KW = 2; c->cls[1].KW = 6;
+    if (hipStreamCreate(&c->st) != hipSuccess || hipHostMalloc((void**)&c->h_ctr, 128) != hipSuccess) {
+        fail(nullptr, MIRGE_E_HIP, "cannot create stream / pinned buffer"); delete c; return nullptr;
+    }
+    // miRge.pl:326, 333-339
+    static const mirge_round def[5] = {{MIRGE_LIB_MIRNA, 26, 0, 0, 0, 28, 0, 2}, {MIRGE_LIB_HAIRPIN, 0, 25, 0, 0, 28, 1, 2},
+                                       {MIRGE_LIB_OTHER, 0, 0, 0, 0, 28, 1, 2},  {MIRGE_LIB_MRNA, 0, 0, 0, 0, 28, 0, 2},
+                                       {MIRGE_LIB_MIRNA, 0, 0, 1, 2, 15, 2, 2}};
+    c->n_rounds = 5;
+    for (int i = 0; i < 5; ++i) c->rounds[i] = def[i];
+    if (species_dir) {
+        static const char* nm[MIRGE_N_LIBS] = {"mirna", "hairpin", "other", "mrna"};
+        for (int l = 0; l < MIRGE_N_LIBS; ++l) {
+            std::string base = std::string(species_dir) + "/" + nm[l];
+            std::string path = base + ".fa";
+            FILE* f = fopen(path.c_str(), "rb");
+            if (!f) { path = base + ".fasta"; f = fopen(path.c_str(), "rb"); }
+            if (!f) {
+                fail(nullptr, MIRGE_E_IO, "cannot find " + base + ".fa (the sequences must sit beside the .ebwt files)");
+                mirge_close(c); return nullptr;
+            }
+            fclose(f);
+            if (load_fasta(c, l, path.c_str()) != MIRGE_OK) { g_open_error = c->err; mirge_close(c); return nullptr; }
+        }
+    }
+    return c;
+}
+
+void mirge_close(mirge_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->st) (void)hipStreamSynchronize(c->st);
+    for (auto& L : c->libs) L.release();
+    for (auto& C : c->cls) C.release();
+    DevBuf* ws[] = {&c->lslots, &c->cnt, &c->rep, &c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
+                    &c->hist, &c->d_stats, &c->d_quant, &c->d_iscan, &c->d_cat, &c->d_len, &c->d_tu};
+    for (auto* b : ws) b->release();
+    for (auto& k : c->kt) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
+    if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    if (c->st) (void)hipStreamDestroy(c->st);
+    delete c;
+}
+
+int32_t mirge_reset(mirge_ctx* c, int32_t n_samples) {
+    if (!c) return MIRGE_E_ARG;
+    if (n_samples < 1) return fail(c, MIRGE_E_ARG, "n_samples must be >= 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->S = n_samples;
+    for (auto& C : c->cls) C.reset();
+    c->annotated = false; c->counts_valid = false; c->host_valid = false;
+    return MIRGE_OK;
+}
+
+int32_t mirge_load_library_fasta(mirge_ctx* c, int32_t lib, const char* path) {
+    if (!c || !path) return MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return load_fasta(c, lib, path);
+}
+
+int32_t mirge_load_library_mem(mirge_ctx* c, int32_t lib, int32_t n, const char* names, const char* seqs, const uint64_t* offs) {
+    if (!c || n < 0 || (n > 0 && (!names || !seqs)) || !offs) return c ? fail(c, MIRGE_E_ARG, "bad library arguments") : MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<std::string> nm; nm.reserve((size_t)n);
+    const char* p = names;
+    for (int i = 0; i < n; ++i) { nm.emplace_back(p); p += nm.back().size() + 1; }
+    return load_library(c, lib, std::move(nm), seqs, offs);
+}
+
+int32_t mirge_lib_size(const mirge_ctx* c, int32_t lib) {
+    if (!c || lib < 0 || lib >= MIRGE_N_LIBS || !c->libs[lib].loaded) return MIRGE_E_ARG;
+    return (int32_t)c->libs[lib].names.size();
+}
+const char* mirge_lib_name(const mirge_ctx* c, int32_t lib, int32_t idx) {
+    if (!c || lib < 0 || lib >= MIRGE_N_LIBS || idx < 0 || (size_t)idx >= c->libs[lib].names.size()) return nullptr;
+    return c->libs[lib].names[(size_t)idx].c_str();
+}
+const char* mirge_lib_short_name(const mirge_ctx* c, int32_t lib, int32_t idx) {
+    if (!c || lib < 0 || lib >= MIRGE_N_LIBS || idx < 0 || (size_t)idx >= c->libs[lib].short_names.size()) return nullptr;
+    return c->libs[lib].short_names[(size_t)idx].c_str();
+}
+
+int32_t mirge_set_rounds(mirge_ctx* c, int32_t n, const mirge_round* r) {
+    if (!c) return MIRGE_E_ARG;
+    if (n < 1 || n > MIRGE_MAX_ROUNDS || !r) return fail(c, MIRGE_E_ARG, "between 1 and 8 rounds");
+    for (int i = 0; i < n; ++i) {
+        if (r[i].lib < 0 || r[i].lib >= MIRGE_N_LIBS || r[i].trim5 < 0 || r[i].trim3 < 0 || r[i].seedlen < 1 ||
+            r[i].seedmm < 0 || r[i].seedmm > 3 || r[i].maxmm < 0 || r[i].maxmm > 3)
+            return fail(c, MIRGE_E_ARG, "round " + std::to_string(i + 1) + ": parameter out of range");
+        c->rounds[i] = r[i];
+    }
+    c->n_rounds = n; c->annotated = false; c->counts_valid = false;
+    return MIRGE_OK;
+}
+
+int32_t mirge_collapse_seqs(mirge_ctx* c, const char* seqs, const uint64_t* offs, uint64_t n, int32_t sample) {
+    if (!c || !offs || (n && !seqs)) return c ? fail(c, MIRGE_E_ARG, "null input") : MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return collapse_host(c, seqs, offs, n, sample);
+}
+
+int32_t mirge_collapse_fastq(mirge_ctx* c, const char* path, int32_t sample, uint64_t* n_reads) {
+    if (!c || !path) return MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::string data;
+    int rc = read_file(c, path, data);
+    if (rc) return rc;
+    // miRge.pl:300-304: records of four lines; the key is line 2 with its "\n" removed
+    std::string seqs; std::vector<uint64_t> offs; offs.push_back(0);
+    size_t i = 0, n = data.size();
+    auto next_line = [&](size_t& b, size_t& e) -> bool {
+        if (i >= n) return false;
+        b = i; e = data.find('\n', i); if (e == std::string::npos) e = n;
+        i = e + 1; return true;
+    };
+    size_t b, e;
+    while (next_line(b, e)) {
+        size_t sb = 0, se = 0;
+        if (next_line(sb, se)) seqs.append(data, sb, se - sb);
+        offs.push_back(seqs.size());
+        size_t x, y; next_line(x, y); next_line(x, y);
+    }
+    uint64_t nr = offs.size() - 1;
+    if (n_reads) *n_reads = nr;
+    return collapse_host(c, seqs.data(), offs.data(), nr, sample);
+}
+
+int32_t mirge_pack_dev(mirge_ctx* c, const void* d_seqs, uint32_t width, const void* d_lens, uint64_t n,
+                       void* d_keys16, uint64_t* n16, void* d_keys48, uint64_t* n48) {
+    if (!c || (n && (!d_seqs || !d_lens || !d_keys16 || !d_keys48))) return c ? fail(c, MIRGE_E_ARG, "null device pointer") : MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->ctr.ensure(64, false, 0, c->st));
+    HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 64, c->st));
+    c->h_ctr[0] = c->h_ctr[1] = 0;
+    int rc = pack_launch(c, d_seqs, width, d_lens, n, d_keys16, d_keys48);
+    if (rc) return rc;
+    if (n16) *n16 = n ? c->h_ctr[0] : 0;
+    if (n48) *n48 = n ? c->h_ctr[1] : 0;
+    kt_resolve(c);
+    return MIRGE_OK;
+}
+
+int32_t mirge_collapse_ascii_dev(mirge_ctx* c, const void* d_seqs, uint32_t width, const void* d_lens, uint64_t n, int32_t sample) {
+    if (!c || (n && (!d_seqs || !d_lens))) return c ? fail(c, MIRGE_E_ARG, "null device pointer") : MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->stage16.ensure(std::max<uint64_t>(n, 1) * 16, false, 0, c->st));
+    HIPCHK(c, c->stage48.ensure(std::max<uint64_t>(n, 1) * 48, false, 0, c->st));
+    uint64_t n16 = 0, n48 = 0;
+    int rc = mirge_pack_dev(c, d_seqs, width, d_lens, n, c->stage16.p, &n16, c->stage48.p, &n48);
+    if (rc) return rc;
+    return collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
+}
+
+int32_t mirge_collapse_packed_dev(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, uint64_t n48, int32_t sample) {
+    if (!c || (n16 && !d16) || (n48 && !d48)) return c ? fail(c, MIRGE_E_ARG, "null device pointer") : MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return collapse_packed(c, d16, n16, d48, n48, sample);
+}
+
+int32_t mirge_annotate(mirge_ctx* c) {
+    if (!c) return MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return annotate(c);
+}
+
+int32_t mirge_round_stats(const mirge_ctx* c, int32_t round, uint64_t* processed, uint64_t* aligned, double* seconds) {
+    if (!c || round < 1 || round > c->n_rounds || !c->annotated) return MIRGE_E_ARG;
+    if (processed) *processed = c->stats[round - 1][0];
+    if (aligned) *aligned = c->stats[round - 1][1];
+    if (seconds) *seconds = c->round_ms[round - 1] * 1e-3;
+    return MIRGE_OK;
+}
+
+int32_t mirge_counts(mirge_ctx* c, const uint64_t** quant, const uint64_t** iscan, const uint64_t** category,
+                     const uint64_t** len_hist, const uint64_t** trimmed_uniq) {
+    if (!c) return MIRGE_E_ARG;
+    if (!c->counts_valid) return fail(c, MIRGE_E_ARG, "mirge_counts before mirge_annotate");
+    if (quant) *quant = c->h_quant.data();
+    if (iscan) *iscan = c->h_iscan.data();
+    if (category) *category = c->h_cat.data();
+    if (len_hist) *len_hist = c->h_len.data();
+    if (trimmed_uniq) *trimmed_uniq = c->h_tu.data();
+    return MIRGE_OK;
+}
+
+uint64_t mirge_counts_flat_len(const mirge_ctx* c) {
+    if (!c || !c->libs[MIRGE_LIB_MIRNA].loaded) return 0;
+    uint64_t M = c->libs[MIRGE_LIB_MIRNA].names.size(), S = (uint64_t)c->S;
+    return 2 * M * S + 5 * S + (MIRGE_MAX_READ_LEN + 1) * S + S;
+}
+int32_t mirge_counts_flat_get(mirge_ctx* c, uint64_t* out) {
+    if (!c || !out) return MIRGE_E_ARG;
+    if (!c->counts_valid) return fail(c, MIRGE_E_ARG, "count vectors not computed yet");
+    size_t M = c->libs[MIRGE_LIB_MIRNA].names.size(), S = (size_t)c->S, o = 0;
+    memcpy(out + o, c->h_quant.data(), M * S * 8); o += M * S;
+    memcpy(out + o, c->h_iscan.data(), M * S * 8); o += M * S;
+    memcpy(out + o, c->h_cat.data(), 5 * S * 8); o += 5 * S;
+    memcpy(out + o, c->h_len.data(), (MIRGE_MAX_READ_LEN + 1) * S * 8); o += (MIRGE_MAX_READ_LEN + 1) * S;
+    memcpy(out + o, c->h_tu.data(), S * 8);
+    return MIRGE_OK;
+}
+int32_t mirge_counts_flat_set(mirge_ctx* c, const uint64_t* in) {
+    if (!c || !in) return MIRGE_E_ARG;
+    if (!c->counts_valid) return fail(c, MIRGE_E_ARG, "count vectors not computed yet");
+    size_t M = c->libs[MIRGE_LIB_MIRNA].names.size(), S = (size_t)c->S, o = 0;
+    memcpy(c->h_quant.data(), in + o, M * S * 8); o += M * S;
+    memcpy(c->h_iscan.data(), in + o, M * S * 8); o += M * S;
+    memcpy(c->h_cat.data(), in + o, 5 * S * 8); o += 5 * S;
+    memcpy(c->h_len.data(), in + o, (MIRGE_MAX_READ_LEN + 1) * S * 8); o += (MIRGE_MAX_READ_LEN + 1) * S;
+    memcpy(c->h_tu.data(), in + o, S * 8);
+    return MIRGE_OK;
+}
+
+uint64_t mirge_n_unique(const mirge_ctx* c) { return c ? c->cls[0].U + c->cls[1].U : 0; }
+
+int32_t mirge_export_uniques(mirge_ctx* c, char* seqs, uint32_t stride, uint8_t* lens, int8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb) {
+    if (!c) return MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = fetch_host(c);
+    if (rc) return rc;
+    uint64_t u = 0;
+    for (int k = 0; k < 2; ++k) {
+        int KW = k == 0 ? 2 : 6;
+        for (uint64_t i = 0; i < c->cls[k].U; ++i, ++u) {
+            char buf[128]; int len = 0;
+            decode_key(&c->h_keys[k][(size_t)i * KW], KW, buf, &len);
+            if (seqs) {
+                if ((uint32_t)len > stride) return fail(c, MIRGE_E_ARG, "stride smaller than a unique sequence");
+                memset(seqs + u * stride, 0, stride); memcpy(seqs + u * stride, buf, (size_t)len);
+            }
+            if (lens) lens[u] = (uint8_t)len;
+            if (ann_round) ann_round[u] = (int8_t)c->h_round[k][(size_t)i];
+            if (ann_ref) ann_ref[u] = c->h_ref[k][(size_t)i];
+            if (ann_amb) ann_amb[u] = c->h_amb[k][(size_t)i];
+        }
+    }
+    return MIRGE_OK;
+}
+
+int32_t mirge_unique(mirge_ctx* c, uint64_t i, const char** seq, int32_t ref_idx[MIRGE_MAX_ROUNDS], uint8_t* ambiguous, const uint32_t** counts) {
+    if (!c) return MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = fetch_host(c);
+    if (rc) return rc;
+    uint64_t U0 = c->cls[0].U;
+    if (i >= U0 + c->cls[1].U) return fail(c, MIRGE_E_ARG, "unique index out of range");
+    int k = i < U0 ? 0 : 1; uint64_t j = k ? i - U0 : i; int KW = k ? 6 : 2;
+    char buf[128]; int len = 0;
+    decode_key(&c->h_keys[k][(size_t)j * KW], KW, buf, &len);
+    c->uniq_seq.assign(buf, (size_t)len);
+    if (seq) *seq = c->uniq_seq.c_str();
+    int r = c->h_round[k][(size_t)j];
+    if (ref_idx) { for (int q = 0; q < MIRGE_MAX_ROUNDS; ++q) ref_idx[q] = -1; if (r > 0) ref_idx[r - 1] = c->h_ref[k][(size_t)j]; }
+    if (ambiguous) *ambiguous = (r > 0 && c->h_amb[k][(size_t)j]) ? (uint8_t)(1u << (r - 1)) : 0;
+    if (counts) {
+        c->uniq_counts.assign((size_t)c->S, 0);
+        for (uint64_t e = c->csr_off[(size_t)i]; e < c->csr_off[(size_t)i + 1]; ++e) c->uniq_counts[c->csr_sample[(size_t)e]] += c->csr_count[(size_t)e];
+        *counts = c->uniq_counts.data();
+    }
+    return MIRGE_OK;
+}
+
+uint64_t mirge_n_counts(const mirge_ctx* c) { return c ? c->cls[0].coo_n + c->cls[1].coo_n : 0; }
+
+int32_t mirge_export_counts(mirge_ctx* c, uint64_t* uid, uint32_t* sample, uint32_t* count) {
+    if (!c) return MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = fetch_host(c);
+    if (rc) return rc;
+    uint64_t U = c->cls[0].U + c->cls[1].U, o = 0;
+    for (uint64_t u = 0; u < U; ++u)
+        for (uint64_t e = c->csr_off[(size_t)u]; e < c->csr_off[(size_t)u + 1]; ++e, ++o) {
+            if (uid) uid[o] = u;
+            if (sample) sample[o] = c->csr_sample[(size_t)e];
+            if (count) count[o] = c->csr_count[(size_t)e];
+        }
+    return MIRGE_OK;
+}
+
+int32_t mirge_last_timing(const mirge_ctx* c, double* collapse_ms, double* annotate_ms, double* counts_ms) {
+    if (!c) return MIRGE_E_ARG;
+    if (collapse_ms) *collapse_ms = c->collapse_ms;
+    if (annotate_ms) *annotate_ms = c->annotate_ms;
+    if (counts_ms) *counts_ms = c->counts_ms;
+    return MIRGE_OK;
+}
+
+int32_t mirge_kernel_times(const mirge_ctx* c, const char** names, double* ms, uint64_t* bytes_alg, int32_t cap) {
+    if (!c) return MIRGE_E_ARG;
+    int32_t n = 0;
+    for (auto& k : c->kt) {
+        if (!k.used) continue;
+        if (n < cap) { if (names) names[n] = k.name; if (ms) ms[n] = k.ms; if (bytes_alg) bytes_alg[n] = k.bytes; }
+        ++n;
+    }
+    return n;
+}
+
+}  // extern "C"

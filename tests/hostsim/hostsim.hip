@@ -1,0 +1,75 @@
+// hostsim.hip -- HOST build of the matcher's __host__ __device__ arithmetic (keys.h, and
+// pack_chunk / verify / match_one of kernels.h) so that `pytest -m "not gpu"` can check the bit
+// tricks against the oracle without a GPU.  Test harness only: nothing in the product links it,
+// and the product library has no such entry point.
+#include "../../mirge_amd/csrc/kernels.h"
+#include <vector>
+#include <cstring>
+using namespace mg;
+
+struct SimLib {
+    std::vector<uint64_t> text, bad;
+    std::vector<uint32_t> koff, kpos, ref_start;
+    uint32_t T; int kb;
+    LibDev dev() const { LibDev L; L.text = text.data(); L.bad = bad.data(); L.koff = koff.data(); L.kpos = kpos.data();
+                         L.ref_start = ref_start.data(); L.n_refs = (uint32_t)ref_start.size() - 1; L.T = T; L.kb = kb; return L; }
+};
+
+extern "C" {
+
+// same layout rules as load_library() in mirge_hip.hip; index built with text_kmer()
+void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb) {
+    SimLib* S = new SimLib();
+    uint64_t T = 0;
+    for (int i = 0; i < n; ++i) T += offs[i + 1] - offs[i] + 1;
+    S->text.assign(T / 32 + 10, 0); S->bad.assign(T / 64 + 10, 0); S->ref_start.assign(n + 1, 0);
+    uint64_t p = 0;
+    for (int i = 0; i < n; ++i) {
+        S->ref_start[i] = (uint32_t)p;
+        for (uint64_t j = offs[i]; j < offs[i + 1]; ++j, ++p) {
+            uint8_t ch = (uint8_t)seqs[j]; if (ch >= 'a' && ch <= 'z') ch -= 32;
+            int code = base_code(ch);
+            if (code >= 0 && code < 4) S->text[p >> 5] |= (uint64_t)code << (2 * (p & 31));
+            else S->bad[p >> 6] |= 1ull << (p & 63);
+        }
+        S->bad[p >> 6] |= 1ull << (p & 63); ++p;
+    }
+    S->ref_start[n] = (uint32_t)p; S->T = (uint32_t)T; S->kb = kb;
+    uint64_t nb = 1ull << (2 * kb);
+    S->koff.assign(nb + 1, 0); S->kpos.assign(T ? T : 1, 0);
+    for (uint32_t q = 0; q < T; ++q) S->koff[text_kmer(S->text.data(), q, kb) + 1]++;
+    for (uint64_t b = 0; b < nb; ++b) S->koff[b + 1] += S->koff[b];
+    std::vector<uint32_t> cur(S->koff.begin(), S->koff.end() - 1);
+    for (uint32_t q = 0; q < T; ++q) S->kpos[cur[text_kmer(S->text.data(), q, kb)]++] = q;
+    return S;
+}
+void sim_lib_free(void* s) { delete (SimLib*)s; }
+
+// returns key words: 2 (16-byte key), 6 (48-byte key), or -4 / -5 like the pack kernel's error codes
+int32_t sim_pack(const char* seq, int32_t len, uint64_t* key) {
+    if (len > 124) return -5;
+    uint8_t row[128]; memset(row, 0, sizeof row); memcpy(row, seq, (size_t)len);
+    uint64_t s[4] = {0, 0, 0, 0}, nm[2] = {0, 0}; bool hasN = false, bad = false;
+    for (int c = 0; c < 8; ++c) if (c * 16 < len) {
+        uint32_t wv[4]; memcpy(wv, row + 16 * c, 16);
+        pack_chunk(wv, c, len, s, nm, hasN, bad);
+    }
+    if (bad) return -4;
+    if (!hasN && len <= 56) { key[0] = s[0]; key[1] = s[1] | ((uint64_t)len << 56); return 2; }
+    key[0] = s[0]; key[1] = s[1]; key[2] = s[2]; key[3] = s[3] | ((uint64_t)len << 56); key[4] = nm[0]; key[5] = nm[1];
+    return 6;
+}
+
+// 1 = aligned (ref, amb filled), 0 = not
+int32_t sim_match(void* lib, const uint64_t* key, int32_t kw, const int32_t* round8, int32_t* ref, int32_t* amb) {
+    SimLib* S = (SimLib*)lib;
+    RoundDev P{round8[0], round8[1], round8[2], round8[3], round8[4], round8[5], round8[6], round8[7]};
+    int32_t r = -1; uint32_t a = 0; bool ok;
+    if (kw == 2) ok = match_one<2>(key, S->dev(), P, r, a); else ok = match_one<6>(key, S->dev(), P, r, a);
+    *ref = ok ? r : -1; *amb = ok ? (int32_t)a : 0;
+    return ok ? 1 : 0;
+}
+
+uint32_t sim_key_hash(const uint64_t* key, int32_t kw) { return kw == 2 ? key_hash<2>(key) : key_hash<6>(key); }
+
+}

@@ -1,0 +1,182 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against (a) the golden tables the
+unmodified reference miRge.pl wrote and (b) the CPU oracle on seeded inputs.  Integer work:
+everything is compared bit-exact."""
+import numpy as np
+import pytest
+
+from mirge_amd import capi, synth
+from mirge_amd.driver import MirgeRun
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", util.golden_cases())
+def test_golden_tables(tmp_path, name):
+    """FASTQ -> collapse -> cascade -> count vectors on the device, merge/filter/tables on the host:
+    miR.Counts.csv and miR.RPM.csv byte-identical, mapped/unmapped.csv identical as row sets, and the
+    report's quantStats / annotStats numbers equal to the reference run's."""
+    case = util.golden_case(name)
+    run = MirgeRun(case["species"], case["fastqs"], case["names"])
+    out = str(tmp_path / "out")
+    run.run(out)
+    util.check_run_against_golden(run, case, out)
+    run.ctx.close()
+
+
+def _compare_with_oracle(oracle, libs, samples, use_index=True, nthreads=8):
+    S = len(samples)
+    with capi.Context(None, S, 0) as ctx:
+        util.load_libs_into(ctx, libs)
+        for s, (seqs, lens) in enumerate(samples):
+            ctx.collapse_seqs(seqs, s, lens)
+        ctx.annotate()
+        got = util.gpu_result_dict(ctx)
+        cv = ctx.counts()
+        stats = [ctx.round_stats(r + 1)[:2] for r in range(5)]
+    res = oracle.run_path(util.oracle_libs(libs, oracle), samples, use_index=use_index, nthreads=nthreads,
+                          maxlen=capi.MAX_READ_LEN)
+    exp = util.oracle_result_dict(res)
+    assert len(got) == len(exp)
+    assert got == exp
+    for k in ("quant", "iscan", "cat", "tuniq", "lenhist"):
+        assert np.array_equal(cv[k], res[k]), k
+    assert stats == [(int(a), int(b)) for a, b in res["stats"]]
+    return res
+
+
+def test_tiny_vs_oracle_bruteforce(oracle):
+    libs, _ = synth.make_libraries(synth.Profile.tiny(), 101)
+    samples = [synth.make_reads(libs, 3000, 200 + s) for s in range(3)]
+    res = _compare_with_oracle(oracle, libs, samples, use_index=False)
+    assert (res["ann_round"] > 0).sum() > 500
+
+
+def test_small_multisample_vs_oracle(oracle):
+    libs, _ = synth.make_libraries(synth.Profile.small(), 102)
+    samples = [synth.make_reads(libs, 40000, 300 + s, zipf_perm_seed=900 + s) for s in range(4)]
+    res = _compare_with_oracle(oracle, libs, samples)
+    for r in range(1, 6):
+        assert (res["ann_round"] == r).sum() > 0, r
+
+
+def test_isomir_rich_vs_oracle(oracle):
+    """BASELINE.json configs[3]: isomiR-rich reads (5'/3' variants, 2 mismatches)."""
+    libs, _ = synth.make_libraries(synth.Profile.small(), 103)
+    samples = [synth.make_reads(libs, 60000, 400, synth.Mixture.isomir_rich())]
+    res = _compare_with_oracle(oracle, libs, samples)
+    assert (res["ann_round"] == 5).sum() > 1000
+
+
+def test_medium_vs_oracle_indexed(oracle):
+    libs, _ = synth.make_libraries(synth.Profile.medium(), 104)
+    samples = [synth.make_reads(libs, 300000, 500)]
+    _compare_with_oracle(oracle, libs, samples)
+
+
+def test_edge_cases(oracle):
+    """Empty sample, empty read, every length 1..124, reads with N, low-complexity reads, duplicates
+    across samples, a read present only in a later sample."""
+    rng = np.random.default_rng(7)
+    libs, _ = synth.make_libraries(synth.Profile.tiny(), 105)
+    mir = libs["mirna"]; mr = libs["mrna"]
+    rs = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
+    s0 = [rs(L) for L in range(1, 125)] + [""] + ["A" * 30, "T" * 20, "ACACACACACACACACACAC"]
+    s0 += [mir.seq(0), mir.seq(0), mir.seq(1)[:20], "N" * 20, "ACGTN" * 5]
+    long_m = mr.seq(0)
+    s0 += [long_m[10:10 + L] for L in (56, 57, 64, 65, 100, 124)]
+    s0 += [long_m[200:260][:30] + "N" + long_m[231:260]]
+    s1 = []
+    s2 = [mir.seq(0), rs(40), long_m[10:67], mir.seq(2)] * 3
+    as_arrays = lambda L: L
+    S = 3
+    with capi.Context(None, S, 0) as ctx:
+        util.load_libs_into(ctx, libs)
+        for s, reads in enumerate([s0, s1, s2]):
+            ctx.collapse_seqs(as_arrays(reads), s)
+        ctx.annotate()
+        got = util.gpu_result_dict(ctx)
+        cv = ctx.counts()
+        # the single-unique accessor agrees with the bulk export
+        for i in range(0, ctx.n_unique(), 7):
+            seq, refs, amb, cnt = ctx.unique(i)
+            r, ref, a, c = got[seq]
+            assert tuple(cnt) == c
+            assert [x for x in refs if x >= 0] == ([ref] if r else [])
+    res = oracle.run_path(util.oracle_libs(libs, oracle), [s0, s1, s2], use_index=False, maxlen=capi.MAX_READ_LEN)
+    assert got == util.oracle_result_dict(res)
+    for k in ("quant", "iscan", "cat", "tuniq", "lenhist"):
+        assert np.array_equal(cv[k], res[k]), k
+    assert "" in got and got[""][0] == 0
+
+
+def test_errors_fail_loudly():
+    libs, _ = synth.make_libraries(synth.Profile.tiny(), 106)
+    with capi.Context(None, 1, 0) as ctx:
+        util.load_libs_into(ctx, libs)
+        with pytest.raises(capi.MirgeError) as e:
+            ctx.collapse_seqs(["ACGT", "ACGU"], 0)
+        assert e.value.code == -4
+        with pytest.raises(capi.MirgeError) as e:
+            ctx.collapse_seqs(["A" * 125], 0)
+        assert e.value.code == -5
+        with pytest.raises(capi.MirgeError):
+            ctx.collapse_seqs(["ACGT"], 3)
+        with pytest.raises(capi.MirgeError):
+            ctx.counts()
+    with capi.Context(None, 1, 0) as ctx:
+        ctx.collapse_seqs(["ACGT"], 0)
+        with pytest.raises(capi.MirgeError):
+            ctx.annotate()                      # libraries not loaded
+    with pytest.raises(capi.MirgeError):
+        capi.Context("/nonexistent/species", 1, 0)
+
+
+def test_device_resident_path_and_reset(oracle):
+    """The configuration bench.py times: ASCII matrix resident in HBM -> mirge_pack_dev ->
+    mirge_collapse_packed_dev -> annotate, twice through mirge_reset (second run smaller)."""
+    import torch
+    libs, _ = synth.make_libraries(synth.Profile.small(), 107)
+    olibs = util.oracle_libs(libs, oracle)
+    with capi.Context(None, 1, 0) as ctx:
+        util.load_libs_into(ctx, libs)
+        for n, seed in ((50000, 600), (12000, 601)):
+            seqs, lens = synth.make_reads(libs, n, seed)
+            d_seqs = torch.from_numpy(seqs).cuda(); d_lens = torch.from_numpy(lens).cuda()
+            k16 = torch.empty((n, 2), dtype=torch.int64, device="cuda"); k48 = torch.empty((n, 6), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            n16, n48 = ctx.pack_dev(d_seqs.data_ptr(), seqs.shape[1], d_lens.data_ptr(), n, k16.data_ptr(), k48.data_ptr())
+            assert n16 + n48 == n and n48 == int(((seqs == ord("N")).any(axis=1)).sum())
+            ctx.reset()
+            ctx.collapse_packed_dev(k16.data_ptr(), n16, k48.data_ptr(), n48, 0)
+            ctx.annotate()
+            got = util.gpu_result_dict(ctx)
+            cv = ctx.counts()
+            res = oracle.run_path(olibs, [(seqs, lens)], use_index=True, nthreads=8, maxlen=capi.MAX_READ_LEN)
+            assert got == util.oracle_result_dict(res)
+            for k in ("quant", "iscan", "cat", "tuniq", "lenhist"):
+                assert np.array_equal(cv[k], res[k]), k
+            # same answer from the ASCII-resident entry point
+            ctx.reset()
+            ctx.collapse_ascii_dev(d_seqs.data_ptr(), seqs.shape[1], d_lens.data_ptr(), n, 0)
+            ctx.annotate()
+            assert util.gpu_result_dict(ctx) == got
+
+
+def test_partition_invariance(oracle):
+    """Shards of one read set (as bench.py --gpus N deals them) sum to the unsharded count vectors."""
+    libs, _ = synth.make_libraries(synth.Profile.small(), 108)
+    seqs, lens = synth.make_reads(libs, 80000, 700)
+    flats = []
+    for nshard in (1, 2, 4):
+        tot = None
+        for r in range(nshard):
+            with capi.Context(None, 1, 0) as ctx:
+                util.load_libs_into(ctx, libs)
+                ctx.collapse_seqs(seqs[r::nshard], 0, lens[r::nshard])
+                ctx.annotate()
+                f = ctx.counts_flat()
+            # trimmedUniq (last S entries) counts uniques per shard, not additive: leave it out
+            tot = f[:-1].copy() if tot is None else tot + f[:-1]
+        flats.append(tot)
+    assert np.array_equal(flats[0], flats[1]) and np.array_equal(flats[0], flats[2])
