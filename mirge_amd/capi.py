@@ -44,6 +44,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (soname libamdhip64.so.7).
+    # Importing torch first makes the loader bind libmirge_hip.so's NEEDED libamdhip64.so.7 to that
+    # copy; the other order leaves two runtimes in the process and torch then finds no GPU.
+    # Standalone callers (the Perl host, tools/mirge-bowtie) use the system ROCm runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
     L = C.CDLL(LIB_PATH)
