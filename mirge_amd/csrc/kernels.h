@@ -167,40 +167,77 @@ k_collapse_local(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* lslots
 // first (read-only here); unseen keys are appended to ukeys at U0 + atomic rank.
 // ctr: [0] = new uniques appended, [1] = entries emitted.  gid_of (nullable): unique id per
 // representative read index.
+// A single hot counter takes ~12 ns per atomic on this chip, so ranks are formed per 2048-element tile
+// (block scan in LDS) and each tile costs one atomic per counter.
+constexpr int EMIT_PER = 8;
 template <int KW>
 __global__ void __launch_bounds__(256)
 k_collapse_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ cnt, uint32_t n,
                 const uint32_t* __restrict__ gslots, uint32_t gmask, uint64_t* ukeys, uint32_t U0,
                 uint32_t* coo_g, uint32_t* coo_c, unsigned long long* ctr, uint32_t* gid_of) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t c = cnt[i];
-    if (c == 0) return;
-    uint64_t k[KW];
+    __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t s_base[2];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * (256u * EMIT_PER);
+    uint32_t c[EMIT_PER], g[EMIT_PER];
+    uint32_t nrep = 0, nnew = 0;
 #pragma unroll
-    for (int w = 0; w < KW; ++w) k[w] = keys[(uint64_t)i * KW + w];
-    uint32_t g = EMPTY;
-    if (gslots) {
-        uint32_t h = (key_hash<KW>(k) >> 7) & gmask;
-        for (;;) {
-            uint32_t o = gslots[h];
-            if (o == EMPTY) break;
-            uint64_t ok[KW];
+    for (int e = 0; e < EMIT_PER; ++e) {
+        uint32_t i = base + e * 256 + tid;
+        c[e] = i < n ? cnt[i] : 0u;
+        g[e] = EMPTY;
+        if (c[e] && gslots) {
+            uint64_t k[KW];
 #pragma unroll
-            for (int w = 0; w < KW; ++w) ok[w] = ukeys[(uint64_t)o * KW + w];
-            if (key_eq<KW>(ok, k)) { g = o; break; }
-            h = (h + 1) & gmask;
+            for (int w = 0; w < KW; ++w) k[w] = keys[(uint64_t)i * KW + w];
+            uint32_t h = (key_hash<KW>(k) >> 7) & gmask;
+            for (;;) {
+                uint32_t o = gslots[h];
+                if (o == EMPTY) break;
+                uint64_t ok[KW];
+#pragma unroll
+                for (int w = 0; w < KW; ++w) ok[w] = ukeys[(uint64_t)o * KW + w];
+                if (key_eq<KW>(ok, k)) { g[e] = o; break; }
+                h = (h + 1) & gmask;
+            }
         }
+        nrep += c[e] != 0;
+        nnew += (c[e] != 0) && g[e] == EMPTY;
     }
-    if (g == EMPTY) {
-        g = U0 + (uint32_t)atomicAdd(&ctr[0], 1ull);
+    // block exclusive scan of (nrep | nnew << 16)
+    uint32_t mine = nrep | (nnew << 16);
+    s_scan[tid] = mine;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        uint32_t t = (int)tid >= o ? s_scan[tid - o] : 0u;
+        __syncthreads();
+        s_scan[tid] += t;
+        __syncthreads();
+    }
+    uint32_t incl = s_scan[tid];
+    if (tid == 255) {
+        uint32_t trep = incl & 0xFFFF, tnew = incl >> 16;
+        s_base[0] = trep ? (uint32_t)atomicAdd(&ctr[1], (unsigned long long)trep) : 0u;
+        s_base[1] = tnew ? (uint32_t)atomicAdd(&ctr[0], (unsigned long long)tnew) : 0u;
+    }
+    __syncthreads();
+    uint32_t prep = s_base[0] + (incl & 0xFFFF) - nrep;
+    uint32_t pnew = s_base[1] + (incl >> 16) - nnew;
 #pragma unroll
-        for (int w = 0; w < KW; ++w) ukeys[(uint64_t)g * KW + w] = k[w];
+    for (int e = 0; e < EMIT_PER; ++e) {
+        if (!c[e]) continue;
+        uint32_t i = base + e * 256 + tid;
+        uint32_t gg = g[e];
+        if (gg == EMPTY) {
+            gg = U0 + pnew++;
+#pragma unroll
+            for (int w = 0; w < KW; ++w) ukeys[(uint64_t)gg * KW + w] = keys[(uint64_t)i * KW + w];
+        }
+        coo_g[prep] = gg;
+        coo_c[prep] = c[e];
+        ++prep;
+        if (gid_of) gid_of[i] = gg;
     }
-    uint32_t p = (uint32_t)atomicAdd(&ctr[1], 1ull);
-    coo_g[p] = g;
-    coo_c[p] = c;
-    if (gid_of) gid_of[i] = g;
 }
 
 // collapse, step C: insert uniques [g0, g1) into the cross-sample table.  They are distinct from
@@ -311,11 +348,11 @@ k_scan_apply(const uint32_t* __restrict__ in, uint64_t n, const uint32_t* __rest
 // which is the one miRge keeps (miRge.pl:429-430).
 struct Best { int sm; uint64_t score; uint32_t minpos, maxpos; };
 
+// One candidate window [w, w+l) on one strand: valid?  (mismatch counts out)
 template <int SW, bool HASN>
-MG_HD void verify(const LibDev& L, const Oriented<SW>& q, const uint64_t (&nsp)[SW],
-                                       const uint64_t (&seedm)[SW], int nN, int nNseed,
-                                       int64_t w, int fw, const RoundDev& P, Best& B) {
-    if (w < 0 || w + q.l > (int64_t)L.T) return;
+MG_HD bool window_ok(const LibDev& L, const Oriented<SW>& q, const uint64_t (&nsp)[SW], const uint64_t (&seedm)[SW],
+                     int nN, int nNseed, int64_t w, const RoundDev& P, int& sm_out, int& tm_out) {
+    if (w < 0 || w + q.l > (int64_t)L.T) return false;
     uint32_t wi = (uint32_t)(w >> 5); int bs = (int)(w & 31) * 2;
     uint64_t t[SW + 1];
 #pragma unroll
@@ -330,7 +367,7 @@ MG_HD void verify(const LibDev& L, const Oriented<SW>& q, const uint64_t (&nsp)[
         tm += popc64(d);
         sm += popc64(d & seedm[i]);
     }
-    if (tm > P.maxmm || sm > P.seedmm) return;
+    if (tm > P.maxmm || sm > P.seedmm) return false;
     // reference N / reference boundary inside the window?
     uint32_t bi = (uint32_t)(w >> 6); int sh = (int)(w & 63);
     uint64_t b0 = L.bad[bi], b1 = L.bad[bi + 1];
@@ -341,16 +378,18 @@ MG_HD void verify(const LibDev& L, const Oriented<SW>& q, const uint64_t (&nsp)[
         uint64_t r1 = sh ? (b1 >> sh) | (b2 << (64 - sh)) : b1;
         any |= r1 & ones(q.l - 64);
     }
-    if (any) return;
-    uint64_t score = ((uint64_t)(3 - sm) << 35) | ((uint64_t)tm << 33) | ((uint64_t)w << 1) | (uint64_t)fw;
-    uint32_t pw = (uint32_t)w;
-    if (sm < B.sm) { B.sm = sm; B.score = score; B.minpos = pw; B.maxpos = pw; }
-    else if (sm == B.sm) {
-        B.score = score > B.score ? score : B.score;
-        B.minpos = pw < B.minpos ? pw : B.minpos;
-        B.maxpos = pw > B.maxpos ? pw : B.maxpos;
-    }
+    if (any) return false;
+    sm_out = sm; tm_out = tm;
+    return true;
 }
+
+// Three order keys of a valid alignment; 0 = none.  Larger stratum field = fewer seed mismatches.
+//   score : (4-sm, tm, w, fw)  -> its maximum is the representative (hypothesis H1)
+//   kmax  : (4-sm, w)          -> max position inside the best stratum
+//   kmin  : (4-sm, ~w)         -> min position inside the best stratum
+MG_HD uint64_t hit_score(int sm, int tm, uint32_t w, int fw) { return ((uint64_t)(4 - sm) << 36) | ((uint64_t)tm << 33) | ((uint64_t)w << 1) | (uint64_t)fw; }
+MG_HD uint64_t hit_kmax(int sm, uint32_t w) { return ((uint64_t)(4 - sm) << 32) | w; }
+MG_HD uint64_t hit_kmin(int sm, uint32_t w) { return ((uint64_t)(4 - sm) << 32) | (0xFFFFFFFFu - w); }
 
 // 1-bit mask -> the same bits at even positions of two words
 MG_HD uint64_t spread32(uint32_t v) {
@@ -369,77 +408,236 @@ MG_HD uint32_t ref_of(const LibDev& L, uint32_t pos) {
     return lo;
 }
 
+constexpr int MAXP = 4;                         // pieces per strand: maxmm + 1 <= 4
+
+// A read prepared for one round: both orientations, seed length, pigeonhole pieces.
+template <int SW> struct Query {
+    Oriented<SW> q[2];                          // [1] forward, [0] reverse complement
+    int l, s, span, np;
+    bool ok;                                    // false: bowtie skips the read (empty / l <= seedmm)
+};
+template <int KW>
+MG_HD void query_setup(const uint64_t* key, const RoundDev& P, Query<KeyTraits<KW>::SW>& Q) {
+    constexpr int SW = KeyTraits<KW>::SW;
+    key_to_read<KW>(key, P.trim5, P.trim3, Q.q[1]);
+    const int l = Q.q[1].l;
+    Q.l = l; Q.ok = !(l <= 0 || l <= P.seedmm);
+    if (!Q.ok) { Q.s = 0; Q.span = 0; Q.np = 0; return; }
+    revcomp<SW>(Q.q[1], Q.q[0]);
+    const int s = P.seedlen < l ? P.seedlen : l;
+    // pigeonhole: <= seedmm mismatches in the seed and <= maxmm overall, so one of (A) seedmm+1 pieces of
+    // the seed or (B) maxmm+1 pieces of the whole read matches exactly; take the longer pieces
+    const int nA = (P.seedmm < P.maxmm ? P.seedmm : P.maxmm) + 1, nB = P.maxmm + 1;
+    Q.s = s; Q.span = s; Q.np = nA;
+    if (l / nB > s / nA) { Q.span = l; Q.np = nB; }
+}
+// per-strand constants of the mismatch count
+template <int SW, bool HASN> struct Strand { uint64_t seedm[SW], nsp[SW]; int nN, nNseed; bool ok; };
+template <int SW, bool HASN>
+MG_HD void strand_setup(const Oriented<SW>& o, int fw, int l, int s, const RoundDev& P, Strand<SW, HASN>& S) {
+    range_mask<SW>(fw ? 0 : l - s, fw ? s : l, S.seedm);
+    S.nN = 0; S.nNseed = 0; S.ok = true;
+    if (HASN) {
+#pragma unroll
+        for (int i = 0; i < SW; ++i) S.nsp[i] = spread32((uint32_t)(o.n[i >> 1] >> (32 * (i & 1))));
+#pragma unroll
+        for (int i = 0; i < SW; ++i) { S.nN += popc64(S.nsp[i]); S.nNseed += popc64(S.nsp[i] & S.seedm[i]); }
+        S.ok = !(S.nN > P.maxmm || S.nNseed > P.seedmm);
+    } else {
+#pragma unroll
+        for (int i = 0; i < SW; ++i) S.nsp[i] = 0;
+    }
+}
+// piece p of strand fw -> where it sits in the oriented read (qs) and its bucket range [b0, b1] in koff
+template <int SW, bool HASN>
+MG_HD bool piece_buckets(const Query<SW>& Q, const Oriented<SW>& o, int kb, int fw, int p, int& qs, uint64_t& b0, uint64_t& b1) {
+    if (p >= Q.np) return false;
+    int ps = Q.span * p / Q.np, pe = Q.span * (p + 1) / Q.np;
+    qs = fw ? ps : Q.l - pe;
+    int kq = pe - ps < kb ? pe - ps : kb;
+    if (kq <= 0) return false;
+    if (HASN && n_in_range<SW>(o, qs, kq)) return false;      // a piece holding a read N is not the exact one
+    uint32_t code = kmer_code<SW>(o, qs, kq);
+    int sh = 2 * (kb - kq);
+    b0 = (uint64_t)code << sh; b1 = ((uint64_t)code + 1) << sh;
+    return true;
+}
+
+// Serial form of the matcher (one read, all candidates in turn): the definition the kernel below
+// parallelises, and what tests/hostsim runs on the CPU.
 template <int KW>
 __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, const RoundDev& P, int32_t& ref, uint32_t& amb) {
     constexpr int SW = KeyTraits<KW>::SW;
     constexpr bool HASN = KeyTraits<KW>::HASN;
-    Oriented<SW> q[2];                      // [1] forward, [0] reverse complement
-    key_to_read<KW>(key, P.trim5, P.trim3, q[1]);
-    const int l = q[1].l;
-    if (l <= 0 || l <= P.seedmm) return false;          // bowtie skips such reads
-    revcomp<SW>(q[1], q[0]);
-    const int s = P.seedlen < l ? P.seedlen : l;
-    const int nA = (P.seedmm < P.maxmm ? P.seedmm : P.maxmm) + 1, nB = P.maxmm + 1;
-    int span = s, np = nA;
-    if (l / nB > s / nA) { span = l; np = nB; }
-    Best B; B.sm = 99; B.score = 0; B.minpos = 0; B.maxpos = 0;
+    Query<SW> Q;
+    query_setup<KW>(key, P, Q);
+    if (!Q.ok) return false;
+    uint64_t score = 0, kmax = 0, kmin = 0;
     for (int fw = 1; fw >= 0; --fw) {
-        const Oriented<SW>& o = q[fw];
-        uint64_t seedm[SW], nsp[SW];
-        range_mask<SW>(fw ? 0 : l - s, fw ? s : l, seedm);
-        int nN = 0, nNseed = 0;
-        if (HASN) {
-#pragma unroll
-            for (int i = 0; i < SW; ++i) nsp[i] = spread32((uint32_t)(o.n[i >> 1] >> (32 * (i & 1))));
-#pragma unroll
-            for (int i = 0; i < SW; ++i) { nN += popc64(nsp[i]); nNseed += popc64(nsp[i] & seedm[i]); }
-            if (nN > P.maxmm || nNseed > P.seedmm) continue;
-        } else {
-#pragma unroll
-            for (int i = 0; i < SW; ++i) nsp[i] = 0;
-        }
-        for (int p = 0; p < np; ++p) {
-            int ps = span * p / np, pe = span * (p + 1) / np;
-            int qs = fw ? ps : l - pe;
-            int kq = pe - ps < L.kb ? pe - ps : L.kb;
-            if (kq <= 0) continue;
-            if (HASN && n_in_range<SW>(o, qs, kq)) continue;   // a piece holding a read N is not the exact one
-            uint32_t code = kmer_code<SW>(o, qs, kq);
-            int sh = 2 * (L.kb - kq);
-            uint32_t lo = L.koff[(uint64_t)code << sh], hi = L.koff[((uint64_t)code + 1) << sh];
-            for (uint32_t c = lo; c < hi; ++c)
-                verify<SW, HASN>(L, o, nsp, seedm, nN, nNseed, (int64_t)L.kpos[c] - qs, fw, P, B);
+        const Oriented<SW>& o = Q.q[fw];
+        Strand<SW, HASN> S;
+        strand_setup<SW, HASN>(o, fw, Q.l, Q.s, P, S);
+        if (!S.ok) continue;
+        for (int p = 0; p < Q.np; ++p) {
+            int qs; uint64_t b0, b1;
+            if (!piece_buckets<SW, HASN>(Q, o, L.kb, fw, p, qs, b0, b1)) continue;
+            uint32_t lo = L.koff[b0], hi = L.koff[b1];
+            for (uint32_t c = lo; c < hi; ++c) {
+                int64_t w = (int64_t)L.kpos[c] - qs; int sm, tm;
+                if (window_ok<SW, HASN>(L, o, S.nsp, S.seedm, S.nN, S.nNseed, w, P, sm, tm)) {
+                    uint64_t a = hit_score(sm, tm, (uint32_t)w, fw), b = hit_kmax(sm, (uint32_t)w), d = hit_kmin(sm, (uint32_t)w);
+                    score = a > score ? a : score; kmax = b > kmax ? b : kmax; kmin = d > kmin ? d : kmin;
+                }
+            }
         }
     }
-    if (B.sm == 99) return false;
-    uint32_t pos = (uint32_t)(B.score >> 1);
-    ref = (int32_t)ref_of(L, pos);
-    amb = ref_of(L, B.minpos) != ref_of(L, B.maxpos);
+    if (!score) return false;
+    ref = (int32_t)ref_of(L, (uint32_t)(score >> 1));
+    amb = ref_of(L, (uint32_t)kmax) != ref_of(L, 0xFFFFFFFFu - (uint32_t)kmin);
     return true;
 }
 
 // One cascade round over the unique table: eligibility (miRge.pl:382-393), match, mark
 // (miRge.pl:445-446).  stats: [0] processed, [1] aligned (miRge.pl:409-413).
-template <int KW>
-__global__ void __launch_bounds__(256)
+//
+// Candidate lists differ by orders of magnitude between reads (a 4-nt seed piece of a 13-nt isomiR
+// query against the miRNA library has ~280 candidates, a 14-nt piece ~1), so a thread-per-read loop
+// runs at the pace of the unluckiest lane.  The block therefore works in three phases:
+//   1. every thread prepares its read, looks up all its piece ranges, verifies the short lists
+//      (<= thr candidates) itself and queues the long ones in LDS;
+//   2. the waves of the block drain the queue, one entry at a time, 64 candidates per step, the
+//      owner's query being read back from LDS (same address in every lane: a broadcast);
+//   3. every thread reads its result.
+// A valid alignment is recorded by three LDS atomic max on its owner's keys (hit_score/kmax/kmin);
+// valid alignments are rare next to candidates, so the atomics are off the critical path.
+constexpr int MB = 256;
+constexpr int STAT_SLOTS = 256;                  // per round: [processed | aligned] x STAT_SLOTS words, 64 B apart
+constexpr int QCAP = 768;                        // LDS queue entries per block; a full queue falls back to the serial loop
+template <int KW, int RN>
+__global__ void __launch_bounds__(MB)
 k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref,
-              uint8_t* ann_amb, LibDev L, RoundDev P, int round_no, unsigned long long* stats) {
-    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= U) return;
-    if (ann_round[u] != 0) return;
+              uint8_t* ann_amb, LibDev L, RoundDev P, int thr, unsigned long long* stats) {
+    constexpr int SW = KeyTraits<KW>::SW, NW = KeyTraits<KW>::NW;
+    constexpr bool HASN = KeyTraits<KW>::HASN;
+    constexpr int QW = 2 * SW + (HASN ? 2 * NW : 0);
+    __shared__ unsigned long long s_best[3 * MB];
+    __shared__ uint64_t s_q[MB * QW];
+    __shared__ int s_ls[MB];
+    __shared__ uint4 s_queue[QCAP];
+    __shared__ uint32_t s_qn, s_next;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t u = blockIdx.x * MB + tid;
+    bool active = false;
     uint64_t k[KW];
+    if (u < U && ann_round[u] == 0) {
 #pragma unroll
-    for (int w = 0; w < KW; ++w) k[w] = ukeys[(uint64_t)u * KW + w];
-    int len = key_len<KW>(k);
-    if (P.len_lt && !(len < P.len_lt)) return;
-    if (P.len_gt && !(len > P.len_gt)) return;
-    atomicAdd(&stats[0], 1ull);
-    int32_t ref; uint32_t amb;
-    if (match_one<KW>(k, L, P, ref, amb)) {
-        ann_round[u] = (uint8_t)round_no;
-        ann_ref[u] = ref;
-        ann_amb[u] = (uint8_t)amb;
-        atomicAdd(&stats[1], 1ull);
+        for (int w = 0; w < KW; ++w) k[w] = ukeys[(uint64_t)u * KW + w];
+        int len = key_len<KW>(k);
+        active = !(P.len_lt && !(len < P.len_lt)) && !(P.len_gt && !(len > P.len_gt));
+    }
+    if (!__syncthreads_or(active)) return;
+    s_best[tid] = 0; s_best[MB + tid] = 0; s_best[2 * MB + tid] = 0;
+    if (tid == 0) { s_qn = 0; s_next = 0; }
+    __syncthreads();
+
+    // ---- phase 1
+    Query<SW> Q; Q.ok = false;
+    if (active) query_setup<KW>(k, P, Q);
+    if (Q.ok) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+#pragma unroll
+            for (int i = 0; i < SW; ++i) s_q[tid * QW + f * SW + i] = Q.q[f].s[i];
+            if (HASN) {
+#pragma unroll
+                for (int i = 0; i < NW; ++i) s_q[tid * QW + 2 * SW + f * NW + i] = Q.q[f].n[i];
+            }
+        }
+        s_ls[tid] = Q.l | (Q.s << 8);
+        int qs[2][MAXP]; uint32_t lo[2][MAXP], hi[2][MAXP];
+        Strand<SW, HASN> S[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            strand_setup<SW, HASN>(Q.q[f], f, Q.l, Q.s, P, S[f]);
+#pragma unroll
+            for (int p = 0; p < MAXP; ++p) {
+                uint64_t b0 = 0, b1 = 0; qs[f][p] = 0;
+                bool v = S[f].ok && piece_buckets<SW, HASN>(Q, Q.q[f], L.kb, f, p, qs[f][p], b0, b1);
+                lo[f][p] = v ? L.koff[b0] : 0u;
+                hi[f][p] = v ? L.koff[b1] : 0u;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+#pragma unroll
+            for (int p = 0; p < MAXP; ++p) {
+                uint32_t cnt = hi[f][p] - lo[f][p];
+                if (cnt == 0) continue;
+                uint32_t e = QCAP;
+                if (cnt > (uint32_t)thr) { e = atomicAdd(&s_qn, 1u); }
+                if (e < (uint32_t)QCAP) {
+                    s_queue[e] = make_uint4(lo[f][p], hi[f][p], (uint32_t)qs[f][p] | ((uint32_t)f << 8) | (tid << 16), 0u);
+                } else {
+                    for (uint32_t c = lo[f][p]; c < hi[f][p]; ++c) {
+                        int64_t w = (int64_t)L.kpos[c] - qs[f][p]; int sm, tm;
+                        if (window_ok<SW, HASN>(L, Q.q[f], S[f].nsp, S[f].seedm, S[f].nN, S[f].nNseed, w, P, sm, tm)) {
+                            atomicMax(&s_best[tid], (unsigned long long)hit_score(sm, tm, (uint32_t)w, f));
+                            atomicMax(&s_best[MB + tid], (unsigned long long)hit_kmax(sm, (uint32_t)w));
+                            atomicMax(&s_best[2 * MB + tid], (unsigned long long)hit_kmin(sm, (uint32_t)w));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: drain the queue, one entry per wave at a time
+    const uint32_t qn = s_qn < (uint32_t)QCAP ? s_qn : (uint32_t)QCAP;
+    for (;;) {
+        uint32_t e = 0;
+        if (lane == 0) e = atomicAdd(&s_next, 1u);
+        e = __shfl(e, 0);
+        if (e >= qn) break;
+        const uint4 en = s_queue[e];
+        const int eqs = (int)(en.z & 0xFF), f = (int)((en.z >> 8) & 1); const uint32_t owner = en.z >> 16;
+        Oriented<SW> o;
+#pragma unroll
+        for (int i = 0; i < SW; ++i) o.s[i] = s_q[owner * QW + f * SW + i];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) o.n[i] = HASN ? s_q[owner * QW + 2 * SW + f * NW + i] : 0ull;
+        const int ls = s_ls[owner];
+        o.l = ls & 0xFF;
+        Strand<SW, HASN> S;
+        strand_setup<SW, HASN>(o, f, o.l, ls >> 8, P, S);
+        for (uint32_t c = en.x + lane; c < en.y; c += 64) {
+            int64_t w = (int64_t)L.kpos[c] - eqs; int sm, tm;
+            if (window_ok<SW, HASN>(L, o, S.nsp, S.seedm, S.nN, S.nNseed, w, P, sm, tm)) {
+                atomicMax(&s_best[owner], (unsigned long long)hit_score(sm, tm, (uint32_t)w, f));
+                atomicMax(&s_best[MB + owner], (unsigned long long)hit_kmax(sm, (uint32_t)w));
+                atomicMax(&s_best[2 * MB + owner], (unsigned long long)hit_kmin(sm, (uint32_t)w));
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3
+    bool hit = false;
+    if (Q.ok) {
+        unsigned long long score = s_best[tid];
+        if (score) {
+            hit = true;
+            ann_round[u] = (uint8_t)(RN + 1);
+            ann_ref[u] = (int32_t)ref_of(L, (uint32_t)(score >> 1));
+            ann_amb[u] = (uint8_t)(ref_of(L, (uint32_t)s_best[MB + tid]) != ref_of(L, 0xFFFFFFFFu - (uint32_t)s_best[2 * MB + tid]));
+        }
+    }
+    // counters are spread over STAT_SLOTS cache lines: one hot word would cost ~12 ns per wave
+    unsigned long long am = __ballot(active), hm = __ballot(hit);
+    if (lane == 0) {
+        uint32_t slot = (blockIdx.x * 4 + (tid >> 6)) & (STAT_SLOTS - 1);
+        atomicAdd(&stats[(size_t)slot * 8], (unsigned long long)__popcll(am));
+        if (hm) atomicAdd(&stats[(size_t)(STAT_SLOTS + slot) * 8], (unsigned long long)__popcll(hm));
     }
 }
 

@@ -59,6 +59,8 @@ struct Lib {
     void release() { text.release(); bad.release(); koff.release(); kpos.release(); dref.release(); loaded = false; }
 };
 
+constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
+
 struct Segment { int sample; uint64_t start, count; };
 
 // The unique table of one key class (16-byte or 48-byte keys).
@@ -85,6 +87,7 @@ struct mirge_ctx {
     std::string err;
     Lib libs[MIRGE_N_LIBS];
     int n_rounds = 5;
+    int coop_thr = 12;                              // candidate lists longer than this are drained by whole waves
     mirge_round rounds[MIRGE_MAX_ROUNDS];
     Class cls[2];                                   // [0] 16-byte keys, [1] 48-byte keys
     // workspaces
@@ -272,7 +275,7 @@ int collapse_class(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64,
                        d_keys, n, c->lslots.as<uint32_t>(), (uint32_t)(capL - 1), c->cnt.as<uint32_t>(), (uint32_t*)nullptr);
     kt_end(c, tagA, (uint64_t)n * KW * 8);
     kt_begin(c, tagB);
-    hipLaunchKernelGGL((k_collapse_emit<KW>), dim3((n + 255) / 256), dim3(256), 0, c->st,
+    hipLaunchKernelGGL((k_collapse_emit<KW>), dim3((n + 256 * EMIT_PER - 1) / (256 * EMIT_PER)), dim3(256), 0, c->st,
                        d_keys, c->cnt.as<uint32_t>(), n, use_g ? C.gslots.as<uint32_t>() : (const uint32_t*)nullptr,
                        (uint32_t)(C.gcap ? C.gcap - 1 : 0), C.ukeys.as<uint64_t>(), (uint32_t)C.U,
                        C.coo_g.as<uint32_t>() + C.coo_n, C.coo_c.as<uint32_t>() + C.coo_n,
@@ -364,13 +367,31 @@ int collapse_host(mirge_ctx* c, const char* seqs, const uint64_t* offs, uint64_t
 }
 
 // ---- cascade + count vectors
+template <int KW, int RN>
+void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, int thr, int r) {
+    hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((C.U + MB - 1) / MB)), dim3(MB), 0, c->st,
+                       C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
+                       C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats.as<unsigned long long>() + (size_t)r * STAT_WORDS);
+}
+
+// the round number is a template parameter only so that every round is its own kernel symbol in a
+// rocprof trace (the library's own per-round timing and the trace can then be compared)
 template <int KW>
 int annotate_class(mirge_ctx* c, Class& C, int r, const mirge_round& R) {
     if (C.U == 0) return MIRGE_OK;
     RoundDev P{R.lib, R.len_lt, R.len_gt, R.trim5, R.trim3, R.seedlen, R.seedmm, R.maxmm};
-    hipLaunchKernelGGL((k_match_round<KW>), dim3((uint32_t)((C.U + 255) / 256)), dim3(256), 0, c->st,
-                       C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
-                       C.ann_amb.as<uint8_t>(), c->libs[R.lib].dev(), P, r + 1, c->d_stats.as<unsigned long long>() + 2 * r);
+    LibDev L = c->libs[R.lib].dev();
+    int thr = c->coop_thr;
+    switch (r) {
+        case 0: launch_match<KW, 0>(c, C, P, L, thr, r); break;
+        case 1: launch_match<KW, 1>(c, C, P, L, thr, r); break;
+        case 2: launch_match<KW, 2>(c, C, P, L, thr, r); break;
+        case 3: launch_match<KW, 3>(c, C, P, L, thr, r); break;
+        case 4: launch_match<KW, 4>(c, C, P, L, thr, r); break;
+        case 5: launch_match<KW, 5>(c, C, P, L, thr, r); break;
+        case 6: launch_match<KW, 6>(c, C, P, L, thr, r); break;
+        default: launch_match<KW, 7>(c, C, P, L, thr, r); break;
+    }
     HIPCHK(c, hipGetLastError());
     return MIRGE_OK;
 }
@@ -413,13 +434,13 @@ int annotate(mirge_ctx* c) {
     }
     int M = (int)c->libs[MIRGE_LIB_MIRNA].names.size(), S = c->S;
     size_t qn = std::max<size_t>((size_t)M * S, 1);
-    HIPCHK(c, c->d_stats.ensure(MIRGE_MAX_ROUNDS * 16, false, 0, c->st));
+    HIPCHK(c, c->d_stats.ensure(MIRGE_MAX_ROUNDS * STAT_WORDS * 8, false, 0, c->st));
     HIPCHK(c, c->d_quant.ensure(qn * 8, false, 0, c->st));
     HIPCHK(c, c->d_iscan.ensure(qn * 8, false, 0, c->st));
     HIPCHK(c, c->d_cat.ensure((size_t)5 * S * 8, false, 0, c->st));
     HIPCHK(c, c->d_len.ensure((size_t)128 * S * 8, false, 0, c->st));
     HIPCHK(c, c->d_tu.ensure((size_t)S * 8, false, 0, c->st));
-    HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, MIRGE_MAX_ROUNDS * 16, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, MIRGE_MAX_ROUNDS * STAT_WORDS * 8, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_quant.p, 0, qn * 8, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_iscan.p, 0, qn * 8, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_cat.p, 0, (size_t)5 * S * 8, c->st));
@@ -444,8 +465,8 @@ int annotate(mirge_ctx* c) {
     HIPCHK(c, hipEventRecord(e2, c->st));
     c->h_quant.assign(qn, 0); c->h_iscan.assign(qn, 0); c->h_cat.assign((size_t)5 * S, 0);
     c->h_len.assign((size_t)128 * S, 0); c->h_tu.assign((size_t)S, 0);
-    uint64_t hs[MIRGE_MAX_ROUNDS * 2];
-    HIPCHK(c, hipMemcpyAsync(hs, c->d_stats.p, sizeof hs, hipMemcpyDeviceToHost, c->st));
+    std::vector<uint64_t> hraw(MIRGE_MAX_ROUNDS * STAT_WORDS);
+    HIPCHK(c, hipMemcpyAsync(hraw.data(), c->d_stats.p, hraw.size() * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipMemcpyAsync(c->h_quant.data(), c->d_quant.p, (size_t)M * S * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipMemcpyAsync(c->h_iscan.data(), c->d_iscan.p, (size_t)M * S * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipMemcpyAsync(c->h_cat.data(), c->d_cat.p, (size_t)5 * S * 8, hipMemcpyDeviceToHost, c->st));
@@ -457,6 +478,10 @@ int annotate(mirge_ctx* c) {
     (void)hipEventElapsedTime(&ms, e1, e2); c->counts_ms = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     kt_resolve(c);
+    uint64_t hs[MIRGE_MAX_ROUNDS * 2] = {};
+    for (int r = 0; r < c->n_rounds; ++r)
+        for (int w = 0; w < 2; ++w)
+            for (int sl = 0; sl < STAT_SLOTS; ++sl) hs[2 * r + w] += hraw[(size_t)r * STAT_WORDS + ((size_t)w * STAT_SLOTS + sl) * 8];
     for (int r = 0; r < c->n_rounds; ++r) {
         c->stats[r][0] = hs[2 * r]; c->stats[r][1] = hs[2 * r + 1];
         c->round_ms[r] = ktime(c, kRoundNames[r]).ms;
@@ -551,6 +576,7 @@ mirge_ctx* mirge_open(const char* species_dir, int32_t n_samples, int32_t device
                                        {MIRGE_LIB_MIRNA, 0, 0, 1, 2, 15, 2, 2}};
     c->n_rounds = 5;
     for (int i = 0; i < 5; ++i) c->rounds[i] = def[i];
+    if (const char* t = getenv("MIRGE_COOP_THR")) c->coop_thr = std::max(0, atoi(t));
     if (species_dir) {
         static const char* nm[MIRGE_N_LIBS] = {"mirna", "hairpin", "other", "mrna"};
         for (int l = 0; l < MIRGE_N_LIBS; ++l) {
