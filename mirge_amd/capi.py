@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmirge_hip.so")
+LIB_PATH = os.environ.get("MIRGE_HIP_LIB") or os.path.join(HERE, "libmirge_hip.so")   # override: A/B builds only
 
 LIB_MIRNA, LIB_HAIRPIN, LIB_OTHER, LIB_MRNA = 0, 1, 2, 3
 MAX_ROUNDS = 8

@@ -14,13 +14,20 @@ constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 //          (and after) them; >= 8 zero words of padding at the end.
 //   bad  : 1 bit per nt, set on reference N (non-ACGT) and on separators; a window is alignable
 //          iff it holds no set bit, which also keeps it inside one reference.
-//   koff/kpos : CSR k-mer index over every text position p: bucket = code of text[p, p+kb),
-//          first nt most significant, so a shorter prefix is a contiguous bucket range.
+//   koff/kent : CSR k-mer index over every text position p: bucket = code of text[p, p+kb),
+//          first nt most significant, so a shorter prefix is a contiguous bucket range.  Each entry
+//          carries, next to the position, the 48 nt of text around it (KEnt): a candidate is judged
+//          from that one 16-byte load, and the text itself is read only for windows the context
+//          does not cover.
+// index entry: text position + context = 2-bit text[pos - CTX_BACK, pos - CTX_BACK + CTX_NT)
+struct __attribute__((aligned(16))) KEnt { uint32_t pos, c0, c1, c2; };
+constexpr int CTX_BACK = 16, CTX_NT = 48;
+
 struct LibDev {
     const uint64_t* text;
     const uint64_t* bad;
     const uint32_t* koff;
-    const uint32_t* kpos;
+    const KEnt*     kent;
     const uint32_t* ref_start;   // n_refs + 1 text coordinates
     uint32_t n_refs;
     uint32_t T;                  // text length in nt, separators included
@@ -278,10 +285,28 @@ k_kmer_hist(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* his
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < T) atomicAdd(&hist[text_kmer(text, p, kb)], 1u);
 }
+MG_HD KEnt make_kent(const uint64_t* __restrict__ text, uint32_t p) {
+    // 96 bits of text starting at nt p - CTX_BACK (zeros for nt before the text starts)
+    int64_t s0 = (int64_t)p - CTX_BACK;
+    uint32_t st = s0 < 0 ? 0u : (uint32_t)s0;
+    uint32_t wi = st >> 5; int bs = (int)(st & 31) * 2;
+    uint64_t t0 = text[wi], t1 = text[wi + 1], t2 = text[wi + 2];
+    uint64_t lo = bs ? (t0 >> bs) | (t1 << (64 - bs)) : t0;
+    uint64_t hi = bs ? (t1 >> bs) | (t2 << (64 - bs)) : t1;
+    // Branch-free on purpose.  Written as `if (s0 < 0) { ...shifts... }` hipcc (ROCm 7.2) emits an EXEC-masked
+    // block of 64-bit shifts without a skip branch, and on gfx950 that build returned wrong, run-to-run varying
+    // context words for ~8 % of positions (abtest/kent_check3.hip reproduces it); this form is exact.
+    const int sh = s0 < 0 ? (int)(-s0) * 2 : 0;        // 0..32
+    const uint64_t carry = sh ? lo >> (64 - sh) : 0ull;
+    hi = (hi << sh) | carry;
+    lo = lo << sh;
+    KEnt e; e.pos = p; e.c0 = (uint32_t)lo; e.c1 = (uint32_t)(lo >> 32); e.c2 = (uint32_t)hi;
+    return e;
+}
 __global__ void __launch_bounds__(256)
-k_kmer_scatter(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* cursor, uint32_t* kpos) {
+k_kmer_scatter(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* cursor, KEnt* kent) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < T) kpos[atomicAdd(&cursor[text_kmer(text, p, kb)], 1u)] = p;
+    if (p < T) kent[atomicAdd(&cursor[text_kmer(text, p, kb)], 1u)] = make_kent(text, p);
 }
 
 // exclusive scan of uint32, three kernels: per-chunk sums, scan of the sums (one block), apply.
@@ -348,6 +373,21 @@ k_scan_apply(const uint32_t* __restrict__ in, uint64_t n, const uint32_t* __rest
 // which is the one miRge keeps (miRge.pl:429-430).
 struct Best { int sm; uint64_t score; uint32_t minpos, maxpos; };
 
+// no reference N and no reference boundary inside [w, w+l) ?
+template <int SW>
+MG_HD bool window_clean(const LibDev& L, int64_t w, int l) {
+    uint32_t bi = (uint32_t)(w >> 6); int sh = (int)(w & 63);
+    uint64_t b0 = L.bad[bi], b1 = L.bad[bi + 1];
+    uint64_t r0 = sh ? (b0 >> sh) | (b1 << (64 - sh)) : b0;
+    uint64_t any = r0 & ones(l);
+    if (SW > 2) {
+        uint64_t b2 = L.bad[bi + 2];
+        uint64_t r1 = sh ? (b1 >> sh) | (b2 << (64 - sh)) : b1;
+        any |= r1 & ones(l - 64);
+    }
+    return any == 0;
+}
+
 // One candidate window [w, w+l) on one strand: valid?  (mismatch counts out)
 template <int SW, bool HASN>
 MG_HD bool window_ok(const LibDev& L, const Oriented<SW>& q, const uint64_t (&nsp)[SW], const uint64_t (&seedm)[SW],
@@ -368,17 +408,7 @@ MG_HD bool window_ok(const LibDev& L, const Oriented<SW>& q, const uint64_t (&ns
         sm += popc64(d & seedm[i]);
     }
     if (tm > P.maxmm || sm > P.seedmm) return false;
-    // reference N / reference boundary inside the window?
-    uint32_t bi = (uint32_t)(w >> 6); int sh = (int)(w & 63);
-    uint64_t b0 = L.bad[bi], b1 = L.bad[bi + 1];
-    uint64_t r0 = sh ? (b0 >> sh) | (b1 << (64 - sh)) : b0;
-    uint64_t any = r0 & ones(q.l);
-    if (SW > 2) {
-        uint64_t b2 = L.bad[bi + 2];
-        uint64_t r1 = sh ? (b1 >> sh) | (b2 << (64 - sh)) : b1;
-        any |= r1 & ones(q.l - 64);
-    }
-    if (any) return false;
+    if (!window_clean<SW>(L, w, q.l)) return false;
     sm_out = sm; tm_out = tm;
     return true;
 }
@@ -408,12 +438,19 @@ MG_HD uint32_t ref_of(const LibDev& L, uint32_t pos) {
     return lo;
 }
 
-constexpr int MAXP = 4;                         // pieces per strand: maxmm + 1 <= 4
+// Pigeonhole pieces.  An alignment has <= seedmm mismatches in the seed and <= maxmm overall, so one
+// of np = min(seedmm, maxmm) + 1 pieces of the seed matches exactly; when that equals maxmm + 1 the
+// pieces are cut from the whole read instead (longer pieces, same guarantee).  np is the same for
+// every read of a round, so the piece loop is wave-uniform.
+MG_HD int round_np(const RoundDev& P) { return (P.seedmm < P.maxmm ? P.seedmm : P.maxmm) + 1; }
+MG_HD bool round_whole(const RoundDev& P) { return round_np(P) == P.maxmm + 1; }
+// floor(x * p / np) for x <= 4095, p <= np <= 4, without an integer division
+MG_HD int piece_cut(int x, int p, int np) { return (int)(((uint32_t)(x * p) * (uint32_t)(65536 / np + 1)) >> 16); }
 
-// A read prepared for one round: both orientations, seed length, pigeonhole pieces.
+// A read prepared for one round: both orientations, seed length, span the pieces are cut from.
 template <int SW> struct Query {
     Oriented<SW> q[2];                          // [1] forward, [0] reverse complement
-    int l, s, span, np;
+    int l, s, span;
     bool ok;                                    // false: bowtie skips the read (empty / l <= seedmm)
 };
 template <int KW>
@@ -422,14 +459,11 @@ MG_HD void query_setup(const uint64_t* key, const RoundDev& P, Query<KeyTraits<K
     key_to_read<KW>(key, P.trim5, P.trim3, Q.q[1]);
     const int l = Q.q[1].l;
     Q.l = l; Q.ok = !(l <= 0 || l <= P.seedmm);
-    if (!Q.ok) { Q.s = 0; Q.span = 0; Q.np = 0; return; }
+    Q.s = 0; Q.span = 0;
+    if (!Q.ok) { Q.q[0] = Q.q[1]; return; }
     revcomp<SW>(Q.q[1], Q.q[0]);
-    const int s = P.seedlen < l ? P.seedlen : l;
-    // pigeonhole: <= seedmm mismatches in the seed and <= maxmm overall, so one of (A) seedmm+1 pieces of
-    // the seed or (B) maxmm+1 pieces of the whole read matches exactly; take the longer pieces
-    const int nA = (P.seedmm < P.maxmm ? P.seedmm : P.maxmm) + 1, nB = P.maxmm + 1;
-    Q.s = s; Q.span = s; Q.np = nA;
-    if (l / nB > s / nA) { Q.span = l; Q.np = nB; }
+    Q.s = P.seedlen < l ? P.seedlen : l;
+    Q.span = round_whole(P) ? l : Q.s;
 }
 // per-strand constants of the mismatch count
 template <int SW, bool HASN> struct Strand { uint64_t seedm[SW], nsp[SW]; int nN, nNseed; bool ok; };
@@ -448,12 +482,11 @@ MG_HD void strand_setup(const Oriented<SW>& o, int fw, int l, int s, const Round
         for (int i = 0; i < SW; ++i) S.nsp[i] = 0;
     }
 }
-// piece p of strand fw -> where it sits in the oriented read (qs) and its bucket range [b0, b1] in koff
+// piece [ps, pe) (read coordinates) on strand fw -> where it sits in the oriented read (qs) and
+// its bucket range [b0, b1] in koff
 template <int SW, bool HASN>
-MG_HD bool piece_buckets(const Query<SW>& Q, const Oriented<SW>& o, int kb, int fw, int p, int& qs, uint64_t& b0, uint64_t& b1) {
-    if (p >= Q.np) return false;
-    int ps = Q.span * p / Q.np, pe = Q.span * (p + 1) / Q.np;
-    qs = fw ? ps : Q.l - pe;
+MG_HD bool piece_buckets(const Oriented<SW>& o, int l, int kb, int fw, int ps, int pe, int& qs, uint64_t& b0, uint64_t& b1) {
+    qs = fw ? ps : l - pe;
     int kq = pe - ps < kb ? pe - ps : kb;
     if (kq <= 0) return false;
     if (HASN && n_in_range<SW>(o, qs, kq)) return false;      // a piece holding a read N is not the exact one
@@ -461,6 +494,72 @@ MG_HD bool piece_buckets(const Query<SW>& Q, const Oriented<SW>& o, int kb, int 
     int sh = 2 * (kb - kq);
     b0 = (uint64_t)code << sh; b1 = ((uint64_t)code + 1) << sh;
     return true;
+}
+
+// The read of one (orientation, piece), laid out in the coordinates of an index entry's context:
+// read nt i sits at context nt i - a + j0 (a = first read nt the context can cover, j0 = context nt
+// it lines up with).  ra = read bits, m = nts to compare (covered, not a read N), sd = the seed nts
+// among them.  full: the context covers the whole window, so the entry alone decides.
+struct PieceAl { uint64_t ra0, m0, sd0; uint32_t ra1, m1, sd1; uint32_t lo, hi; uint32_t meta; };
+//   meta: owner (bits 0-7) | fw (8) | full (9) | qs (10-16) | l (17-23) | nN (24-26) | nNseed (27-29)
+MG_HD uint32_t pa_meta(uint32_t owner, int fw, bool full, int qs, int l, int nN, int nNseed) {
+    return owner | ((uint32_t)fw << 8) | ((uint32_t)full << 9) | ((uint32_t)qs << 10) | ((uint32_t)l << 17) |
+           ((uint32_t)nN << 24) | ((uint32_t)nNseed << 27);
+}
+// 96 bits of the (SW+1)-word value [0, x] starting at bit `bp` of it (i.e. x shifted left by 64 - bp)
+template <int SW> MG_HD void take96(const uint64_t (&x)[SW], int bp, uint64_t& w0, uint32_t& w1) {
+    uint64_t y[SW + 1];
+    y[0] = 0;
+#pragma unroll
+    for (int i = 0; i < SW; ++i) y[i + 1] = x[i];
+    w0 = bits_at<SW + 1>(y, bp);
+    w1 = (uint32_t)bits_at<SW + 1>(y, bp + 64);
+}
+template <int SW, bool HASN>
+MG_HD void piece_align(const Oriented<SW>& o, const Strand<SW, HASN>& S, int qs, int fw, uint32_t owner, PieceAl& A) {
+    const int a = qs > CTX_BACK ? qs - CTX_BACK : 0;
+    const int j0 = qs < CTX_BACK ? CTX_BACK - qs : 0;
+    int nov = o.l - a; if (nov > CTX_NT - j0) nov = CTX_NT - j0;
+    const int bp = 64 + 2 * a - 2 * j0;                       // >= 32
+    take96<SW>(o.s, bp, A.ra0, A.ra1);
+    const int jlo = j0, jhi = j0 + nov;
+    A.m0 = (ones(2 * jhi) ^ ones(2 * jlo)) & M55;
+    A.m1 = (uint32_t)(ones(2 * jhi - 64) & M55);
+    uint64_t s0; uint32_t s1;
+    take96<SW>(S.seedm, bp, s0, s1);
+    A.sd0 = s0 & A.m0; A.sd1 = s1 & A.m1;
+    if (HASN) {
+        uint64_t n0; uint32_t n1;
+        take96<SW>(S.nsp, bp, n0, n1);
+        A.m0 &= ~n0; A.m1 &= ~n1; A.sd0 &= ~n0; A.sd1 &= ~n1;
+    }
+    A.meta = pa_meta(owner, fw, (a == 0) && (nov == o.l), qs, o.l, S.nN, S.nNseed);
+}
+// One index entry against a prepared piece: 0 = reject, 1 = valid (sm, tm, w set),
+// 2 = passes the context pre-filter but the context does not cover the window: finish on the text.
+template <int SW>
+MG_HD int cand_check(const LibDev& L, const PieceAl& A, const KEnt& e, const RoundDev& P, int& sm, int& tm, uint32_t& w) {
+    const uint32_t qs = (A.meta >> 10) & 127, l = (A.meta >> 17) & 127;
+    if (e.pos < qs) return 0;
+    w = e.pos - qs;
+    if (w + l > L.T) return 0;
+    const uint64_t c64 = (uint64_t)e.c0 | ((uint64_t)e.c1 << 32);
+    uint64_t d0 = c64 ^ A.ra0; d0 = (d0 | (d0 >> 1)) & A.m0;
+    uint32_t d1 = e.c2 ^ A.ra1; d1 = (d1 | (d1 >> 1)) & A.m1;
+    tm = (int)((A.meta >> 24) & 7) + popc64(d0) + popc64((uint64_t)d1);
+    if (tm > P.maxmm) return 0;
+    if (!((A.meta >> 9) & 1)) return 2;
+    sm = (int)((A.meta >> 27) & 7) + popc64(d0 & A.sd0) + popc64((uint64_t)(d1 & A.sd1));
+    if (sm > P.seedmm) return 0;
+    return window_clean<SW>(L, (int64_t)w, (int)l) ? 1 : 0;
+}
+
+// both ends of a bucket range with one 8-byte load when they are neighbours
+MG_HD void koff_range(const uint32_t* __restrict__ koff, uint64_t b0, uint64_t b1, uint32_t& lo, uint32_t& hi) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+    u32x2 v = *reinterpret_cast<const u32x2*>(koff + b0);
+    lo = v.x; hi = v.y;
+    if (b1 != b0 + 1) hi = koff[b1];
 }
 
 // Serial form of the matcher (one read, all candidates in turn): the definition the kernel below
@@ -472,21 +571,26 @@ __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, 
     Query<SW> Q;
     query_setup<KW>(key, P, Q);
     if (!Q.ok) return false;
+    const int np = round_np(P);
     uint64_t score = 0, kmax = 0, kmin = 0;
     for (int fw = 1; fw >= 0; --fw) {
         const Oriented<SW>& o = Q.q[fw];
         Strand<SW, HASN> S;
         strand_setup<SW, HASN>(o, fw, Q.l, Q.s, P, S);
         if (!S.ok) continue;
-        for (int p = 0; p < Q.np; ++p) {
+        for (int p = 0; p < np; ++p) {
             int qs; uint64_t b0, b1;
-            if (!piece_buckets<SW, HASN>(Q, o, L.kb, fw, p, qs, b0, b1)) continue;
-            uint32_t lo = L.koff[b0], hi = L.koff[b1];
-            for (uint32_t c = lo; c < hi; ++c) {
-                int64_t w = (int64_t)L.kpos[c] - qs; int sm, tm;
-                if (window_ok<SW, HASN>(L, o, S.nsp, S.seedm, S.nN, S.nNseed, w, P, sm, tm)) {
-                    uint64_t a = hit_score(sm, tm, (uint32_t)w, fw), b = hit_kmax(sm, (uint32_t)w), d = hit_kmin(sm, (uint32_t)w);
-                    score = a > score ? a : score; kmax = b > kmax ? b : kmax; kmin = d > kmin ? d : kmin;
+            if (!piece_buckets<SW, HASN>(o, Q.l, L.kb, fw, piece_cut(Q.span, p, np), piece_cut(Q.span, p + 1, np), qs, b0, b1)) continue;
+            PieceAl A;
+            piece_align<SW, HASN>(o, S, qs, fw, 0u, A);
+            koff_range(L.koff, b0, b1, A.lo, A.hi);
+            for (uint32_t c = A.lo; c < A.hi; ++c) {
+                int sm, tm; uint32_t w;
+                int r = cand_check<SW>(L, A, L.kent[c], P, sm, tm, w);
+                if (r == 2) r = window_ok<SW, HASN>(L, o, S.nsp, S.seedm, S.nN, S.nNseed, (int64_t)w, P, sm, tm) ? 1 : 0;
+                if (r == 1) {
+                    uint64_t x = hit_score(sm, tm, w, fw), y = hit_kmax(sm, w), z = hit_kmin(sm, w);
+                    score = x > score ? x : score; kmax = y > kmax ? y : kmax; kmin = z > kmin ? z : kmin;
                 }
             }
         }
@@ -503,30 +607,54 @@ __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, 
 // Candidate lists differ by orders of magnitude between reads (a 4-nt seed piece of a 13-nt isomiR
 // query against the miRNA library has ~280 candidates, a 14-nt piece ~1), so a thread-per-read loop
 // runs at the pace of the unluckiest lane.  The block therefore works in three phases:
-//   1. every thread prepares its read, looks up all its piece ranges, verifies the short lists
-//      (<= thr candidates) itself and queues the long ones in LDS;
-//   2. the waves of the block drain the queue, one entry at a time, 64 candidates per step, the
-//      owner's query being read back from LDS (same address in every lane: a broadcast);
+//   1. every thread prepares its read and, piece by piece, looks up the bucket range of both strands,
+//      lays the piece out in context coordinates (PieceAl), checks short lists (<= thr entries)
+//      itself and queues the long ones in LDS;
+//   2. the waves of the block drain the queue, one entry at a time, 64 index entries per step, the
+//      PieceAl being read back from LDS (same address in every lane: a broadcast);
 //   3. every thread reads its result.
 // A valid alignment is recorded by three LDS atomic max on its owner's keys (hit_score/kmax/kmin);
-// valid alignments are rare next to candidates, so the atomics are off the critical path.
+// valid alignments are rare next to candidates, so the atomics are off the critical path.  The kernel
+// is instruction-issue bound (rocprof: SQ_ACTIVE_INST_ANY ~ 90 % of SIMD time), so the inner check
+// is kept to one 16-byte load and ~20 VALU instructions.
 constexpr int MB = 256;
+constexpr int QCAP = 384;                        // LDS queue entries per block; a full queue falls back to the serial loop
 constexpr int STAT_SLOTS = 256;                  // per round: [processed | aligned] x STAT_SLOTS words, 64 B apart
-constexpr int QCAP = 768;                        // LDS queue entries per block; a full queue falls back to the serial loop
+
+__device__ __forceinline__ void record_hit(unsigned long long* s_best, uint32_t owner, int sm, int tm, uint32_t w, int fw) {
+    atomicMax(&s_best[owner], (unsigned long long)hit_score(sm, tm, w, fw));
+    atomicMax(&s_best[MB + owner], (unsigned long long)hit_kmax(sm, w));
+    atomicMax(&s_best[2 * MB + owner], (unsigned long long)hit_kmin(sm, w));
+}
+// rare path: the context did not cover the window; rebuild the owner's read from its key
+template <int KW>
+__device__ __forceinline__ void finish_on_text(const uint64_t* __restrict__ ukeys, uint32_t u, const LibDev& L, const RoundDev& P,
+                                            int fw, uint32_t w, unsigned long long* s_best, uint32_t owner) {
+    constexpr int SW = KeyTraits<KW>::SW;
+    constexpr bool HASN = KeyTraits<KW>::HASN;
+    uint64_t k[KW];
+#pragma unroll
+    for (int i = 0; i < KW; ++i) k[i] = ukeys[(uint64_t)u * KW + i];
+    Query<SW> Q;
+    query_setup<KW>(k, P, Q);
+    Oriented<SW> o = fw ? Q.q[1] : Q.q[0];
+    Strand<SW, HASN> S;
+    strand_setup<SW, HASN>(o, fw, Q.l, Q.s, P, S);
+    int sm, tm;
+    if (window_ok<SW, HASN>(L, o, S.nsp, S.seedm, S.nN, S.nNseed, (int64_t)w, P, sm, tm)) record_hit(s_best, owner, sm, tm, w, fw);
+}
+
 template <int KW, int RN>
 __global__ void __launch_bounds__(MB)
 k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref,
               uint8_t* ann_amb, LibDev L, RoundDev P, int thr, unsigned long long* stats) {
-    constexpr int SW = KeyTraits<KW>::SW, NW = KeyTraits<KW>::NW;
+    constexpr int SW = KeyTraits<KW>::SW;
     constexpr bool HASN = KeyTraits<KW>::HASN;
-    constexpr int QW = 2 * SW + (HASN ? 2 * NW : 0);
     __shared__ unsigned long long s_best[3 * MB];
-    __shared__ uint64_t s_q[MB * QW];
-    __shared__ int s_ls[MB];
-    __shared__ uint4 s_queue[QCAP];
+    __shared__ PieceAl s_queue[QCAP];
     __shared__ uint32_t s_qn, s_next;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t u = blockIdx.x * MB + tid;
+    const uint32_t u0 = blockIdx.x * MB, u = u0 + tid;
     bool active = false;
     uint64_t k[KW];
     if (u < U && ann_round[u] == 0) {
@@ -541,52 +669,41 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     __syncthreads();
 
     // ---- phase 1
-    Query<SW> Q; Q.ok = false;
-    if (active) query_setup<KW>(k, P, Q);
-    if (Q.ok) {
+    Query<SW> Q;
+    if (!active) {
+#pragma unroll
+        for (int w = 0; w < KW; ++w) k[w] = 0;                 // an empty read: Q.ok comes out false
+    }
+    query_setup<KW>(k, P, Q);
+    Q.ok = Q.ok && active;
+    const int np = round_np(P);
+    Strand<SW, HASN> S[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) { strand_setup<SW, HASN>(Q.q[f], f, Q.l, Q.s, P, S[f]); S[f].ok = S[f].ok && Q.ok; }
+    for (int p = 0; p < np; ++p) {
+        const int ps = piece_cut(Q.span, p, np), pe = piece_cut(Q.span, p + 1, np);
+        PieceAl A[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-#pragma unroll
-            for (int i = 0; i < SW; ++i) s_q[tid * QW + f * SW + i] = Q.q[f].s[i];
-            if (HASN) {
-#pragma unroll
-                for (int i = 0; i < NW; ++i) s_q[tid * QW + 2 * SW + f * NW + i] = Q.q[f].n[i];
-            }
-        }
-        s_ls[tid] = Q.l | (Q.s << 8);
-        int qs[2][MAXP]; uint32_t lo[2][MAXP], hi[2][MAXP];
-        Strand<SW, HASN> S[2];
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            strand_setup<SW, HASN>(Q.q[f], f, Q.l, Q.s, P, S[f]);
-#pragma unroll
-            for (int p = 0; p < MAXP; ++p) {
-                uint64_t b0 = 0, b1 = 0; qs[f][p] = 0;
-                bool v = S[f].ok && piece_buckets<SW, HASN>(Q, Q.q[f], L.kb, f, p, qs[f][p], b0, b1);
-                lo[f][p] = v ? L.koff[b0] : 0u;
-                hi[f][p] = v ? L.koff[b1] : 0u;
+            int qs = 0; uint64_t b0 = 0, b1 = 0;
+            A[f].lo = 0; A[f].hi = 0;
+            if (S[f].ok && piece_buckets<SW, HASN>(Q.q[f], Q.l, L.kb, f, ps, pe, qs, b0, b1)) {
+                koff_range(L.koff, b0, b1, A[f].lo, A[f].hi);
+                piece_align<SW, HASN>(Q.q[f], S[f], qs, f, tid, A[f]);
             }
         }
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-#pragma unroll
-            for (int p = 0; p < MAXP; ++p) {
-                uint32_t cnt = hi[f][p] - lo[f][p];
-                if (cnt == 0) continue;
-                uint32_t e = QCAP;
-                if (cnt > (uint32_t)thr) { e = atomicAdd(&s_qn, 1u); }
-                if (e < (uint32_t)QCAP) {
-                    s_queue[e] = make_uint4(lo[f][p], hi[f][p], (uint32_t)qs[f][p] | ((uint32_t)f << 8) | (tid << 16), 0u);
-                } else {
-                    for (uint32_t c = lo[f][p]; c < hi[f][p]; ++c) {
-                        int64_t w = (int64_t)L.kpos[c] - qs[f][p]; int sm, tm;
-                        if (window_ok<SW, HASN>(L, Q.q[f], S[f].nsp, S[f].seedm, S[f].nN, S[f].nNseed, w, P, sm, tm)) {
-                            atomicMax(&s_best[tid], (unsigned long long)hit_score(sm, tm, (uint32_t)w, f));
-                            atomicMax(&s_best[MB + tid], (unsigned long long)hit_kmax(sm, (uint32_t)w));
-                            atomicMax(&s_best[2 * MB + tid], (unsigned long long)hit_kmin(sm, (uint32_t)w));
-                        }
-                    }
-                }
+            const uint32_t cnt = A[f].hi - A[f].lo;
+            if (cnt == 0) continue;
+            uint32_t e = QCAP;
+            if (cnt > (uint32_t)thr) e = atomicAdd(&s_qn, 1u);
+            if (e < (uint32_t)QCAP) { s_queue[e] = A[f]; continue; }
+            for (uint32_t c = A[f].lo; c < A[f].hi; ++c) {
+                int sm, tm; uint32_t w;
+                int r = cand_check<SW>(L, A[f], L.kent[c], P, sm, tm, w);
+                if (r == 1) record_hit(s_best, tid, sm, tm, w, f);
+                else if (r == 2) finish_on_text<KW>(ukeys, u, L, P, f, w, s_best, tid);
             }
         }
     }
@@ -599,24 +716,13 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         if (lane == 0) e = atomicAdd(&s_next, 1u);
         e = __shfl(e, 0);
         if (e >= qn) break;
-        const uint4 en = s_queue[e];
-        const int eqs = (int)(en.z & 0xFF), f = (int)((en.z >> 8) & 1); const uint32_t owner = en.z >> 16;
-        Oriented<SW> o;
-#pragma unroll
-        for (int i = 0; i < SW; ++i) o.s[i] = s_q[owner * QW + f * SW + i];
-#pragma unroll
-        for (int i = 0; i < NW; ++i) o.n[i] = HASN ? s_q[owner * QW + 2 * SW + f * NW + i] : 0ull;
-        const int ls = s_ls[owner];
-        o.l = ls & 0xFF;
-        Strand<SW, HASN> S;
-        strand_setup<SW, HASN>(o, f, o.l, ls >> 8, P, S);
-        for (uint32_t c = en.x + lane; c < en.y; c += 64) {
-            int64_t w = (int64_t)L.kpos[c] - eqs; int sm, tm;
-            if (window_ok<SW, HASN>(L, o, S.nsp, S.seedm, S.nN, S.nNseed, w, P, sm, tm)) {
-                atomicMax(&s_best[owner], (unsigned long long)hit_score(sm, tm, (uint32_t)w, f));
-                atomicMax(&s_best[MB + owner], (unsigned long long)hit_kmax(sm, (uint32_t)w));
-                atomicMax(&s_best[2 * MB + owner], (unsigned long long)hit_kmin(sm, (uint32_t)w));
-            }
+        const PieceAl A = s_queue[e];
+        const uint32_t owner = A.meta & 255; const int f = (int)((A.meta >> 8) & 1);
+        for (uint32_t c = A.lo + lane; c < A.hi; c += 64) {
+            int sm, tm; uint32_t w;
+            int r = cand_check<SW>(L, A, L.kent[c], P, sm, tm, w);
+            if (r == 1) record_hit(s_best, owner, sm, tm, w, f);
+            else if (r == 2) finish_on_text<KW>(ukeys, u0 + owner, L, P, f, w, s_best, owner);
         }
     }
     __syncthreads();

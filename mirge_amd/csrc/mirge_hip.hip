@@ -48,15 +48,15 @@ struct Lib {
     std::vector<uint32_t> ref_start;     // n + 1
     uint64_t T = 0;
     int kb = 0;
-    DevBuf text, bad, koff, kpos, dref;
+    DevBuf text, bad, koff, kent, dref;
     LibDev dev() const {
         LibDev L;
         L.text = text.as<uint64_t>(); L.bad = bad.as<uint64_t>(); L.koff = koff.as<uint32_t>();
-        L.kpos = kpos.as<uint32_t>(); L.ref_start = dref.as<uint32_t>();
+        L.kent = kent.as<KEnt>(); L.ref_start = dref.as<uint32_t>();
         L.n_refs = (uint32_t)names.size(); L.T = (uint32_t)T; L.kb = kb;
         return L;
     }
-    void release() { text.release(); bad.release(); koff.release(); kpos.release(); dref.release(); loaded = false; }
+    void release() { text.release(); bad.release(); koff.release(); kent.release(); dref.release(); loaded = false; }
 };
 
 constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
@@ -188,7 +188,7 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     HIPCHK(c, L.bad.ensure(bwords * 8, false, 0, c->st));
     HIPCHK(c, L.dref.ensure((n + 1) * 4, false, 0, c->st));
     HIPCHK(c, L.koff.ensure((nb + 1) * 4, false, 0, c->st));
-    HIPCHK(c, L.kpos.ensure(std::max<uint64_t>(T, 1) * 4, false, 0, c->st));
+    HIPCHK(c, L.kent.ensure(std::max<uint64_t>(T, 1) * sizeof(KEnt), false, 0, c->st));
     HIPCHK(c, c->hist.ensure((nb + 1) * 4, false, 0, c->st));
     HIPCHK(c, hipMemcpyAsync(L.text.p, text.data(), words * 8, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(L.bad.p, bad.data(), bwords * 8, hipMemcpyHostToDevice, c->st));
@@ -200,7 +200,7 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
         int rc = scan_exclusive(c, c->hist.as<uint32_t>(), L.koff.as<uint32_t>(), nb + 1);
         if (rc) return rc;
         HIPCHK(c, hipMemcpyAsync(c->hist.p, L.koff.p, nb * 4, hipMemcpyDeviceToDevice, c->st));
-        hipLaunchKernelGGL(k_kmer_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, c->hist.as<uint32_t>(), L.kpos.as<uint32_t>());
+        hipLaunchKernelGGL(k_kmer_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, c->hist.as<uint32_t>(), L.kent.as<KEnt>());
         HIPCHK(c, hipGetLastError());
     } else {
         HIPCHK(c, hipMemsetAsync(L.koff.p, 0, (nb + 1) * 4, c->st));
