@@ -37,7 +37,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from mirge_amd import capi, synth
+    from mirge_amd import capi, shard, synth
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -92,10 +92,7 @@ def main():
         ctx.collapse_packed_dev(k16.data_ptr(), n16, k48.data_ptr(), n48, 0)
         ctx.annotate()
         if world > 1:
-            flat = ctx.counts_flat()
-            flat_dev = torch.from_numpy(flat.view(np.int64)).cuda()
-            dist.all_reduce(flat_dev)
-            ctx.set_counts_flat(flat_dev.cpu().numpy().view(np.uint64))
+            ctx.set_counts_flat(shard.allreduce_flat(ctx.counts_flat(), dist, torch.device("cuda", local)))
 
     def fence():
         torch.cuda.synchronize()

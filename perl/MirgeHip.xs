@@ -1,0 +1,120 @@
+/* MirgeHip.xs -- thin XS binding of libmirge_hip.so (include/mirge_hip.h) for the reference's
+ * Perl driver.  One XSUB per C-ABI entry point the hot path of miRge.pl needs; INTEGRATION.md shows
+ * the few lines that replace quantReads / runAnnotationPipeline / summarize (miRge.pl:291-494).
+ * FFI::Platypus is not installed in the image, hence XS (xsubpp + the system perl headers). */
+#define PERL_NO_GET_CONTEXT
+#include "EXTERN.h"
+#include "perl.h"
+#include "XSUB.h"
+#include "../include/mirge_hip.h"
+
+typedef mirge_ctx* MirgeHip;
+
+MODULE = MirgeHip    PACKAGE = MirgeHip    PREFIX = mirge_
+
+PROTOTYPES: DISABLE
+
+MirgeHip
+mirge_open(species_dir, n_samples, device = 0)
+        const char* species_dir
+        int n_samples
+        int device
+    CODE:
+        RETVAL = mirge_open(species_dir, n_samples, device);
+        if (!RETVAL) croak("MirgeHip::open: %s", mirge_last_error(NULL));
+    OUTPUT:
+        RETVAL
+
+void
+mirge_close(ctx)
+        MirgeHip ctx
+
+const char*
+mirge_last_error(ctx)
+        MirgeHip ctx
+
+int
+mirge_lib_size(ctx, lib)
+        MirgeHip ctx
+        int lib
+
+const char*
+mirge_lib_name(ctx, lib, idx)
+        MirgeHip ctx
+        int lib
+        int idx
+
+const char*
+mirge_lib_short_name(ctx, lib, idx)
+        MirgeHip ctx
+        int lib
+        int idx
+
+UV
+mirge_collapse_fastq(ctx, path, sample)
+        MirgeHip ctx
+        const char* path
+        int sample
+    PREINIT:
+        uint64_t n = 0;
+    CODE:
+        if (mirge_collapse_fastq(ctx, path, sample, &n) != MIRGE_OK) croak("MirgeHip::collapse_fastq: %s", mirge_last_error(ctx));
+        RETVAL = (UV)n;
+    OUTPUT:
+        RETVAL
+
+void
+mirge_annotate(ctx)
+        MirgeHip ctx
+    CODE:
+        if (mirge_annotate(ctx) != MIRGE_OK) croak("MirgeHip::annotate: %s", mirge_last_error(ctx));
+
+void
+mirge_round_stats(ctx, round)
+        MirgeHip ctx
+        int round
+    PREINIT:
+        uint64_t p = 0, a = 0; double s = 0;
+    PPCODE:
+        if (mirge_round_stats(ctx, round, &p, &a, &s) != MIRGE_OK) croak("MirgeHip::round_stats: bad round");
+        EXTEND(SP, 3);
+        mPUSHu((UV)p); mPUSHu((UV)a); mPUSHn(s);
+
+UV
+mirge_n_unique(ctx)
+        MirgeHip ctx
+
+void
+mirge_unique(ctx, i, n_samples)
+        MirgeHip ctx
+        UV i
+        int n_samples
+    PREINIT:
+        const char* seq; int32_t ref[MIRGE_MAX_ROUNDS]; uint8_t amb; const uint32_t* cnt; int k;
+    PPCODE:
+        /* returns (sequence, ref_idx[0..4], ambiguous mask, counts[0..S-1]) */
+        if (mirge_unique(ctx, (uint64_t)i, &seq, ref, &amb, &cnt) != MIRGE_OK) croak("MirgeHip::unique: %s", mirge_last_error(ctx));
+        EXTEND(SP, 7 + n_samples);
+        mPUSHp(seq, strlen(seq));
+        for (k = 0; k < 5; ++k) mPUSHi(ref[k]);
+        mPUSHu(amb);
+        for (k = 0; k < n_samples; ++k) mPUSHu(cnt[k]);
+
+void
+mirge_counts(ctx, n_samples)
+        MirgeHip ctx
+        int n_samples
+    PREINIT:
+        const uint64_t *q, *is, *cat, *lh, *tu; AV *aq, *ai, *ac, *al, *at; int M, i;
+    PPCODE:
+        /* returns five array refs: quant[M*S], iscan[M*S], category[5*S], len_hist[125*S], trimmed_uniq[S] */
+        if (mirge_counts(ctx, &q, &is, &cat, &lh, &tu) != MIRGE_OK) croak("MirgeHip::counts: %s", mirge_last_error(ctx));
+        M = mirge_lib_size(ctx, MIRGE_LIB_MIRNA);
+        aq = newAV(); ai = newAV(); ac = newAV(); al = newAV(); at = newAV();
+        for (i = 0; i < M * n_samples; ++i) { av_push(aq, newSVuv((UV)q[i])); av_push(ai, newSVuv((UV)is[i])); }
+        for (i = 0; i < 5 * n_samples; ++i) av_push(ac, newSVuv((UV)cat[i]));
+        for (i = 0; i < (MIRGE_MAX_READ_LEN + 1) * n_samples; ++i) av_push(al, newSVuv((UV)lh[i]));
+        for (i = 0; i < n_samples; ++i) av_push(at, newSVuv((UV)tu[i]));
+        EXTEND(SP, 5);
+        mPUSHs(newRV_noinc((SV*)aq)); mPUSHs(newRV_noinc((SV*)ai)); mPUSHs(newRV_noinc((SV*)ac));
+        mPUSHs(newRV_noinc((SV*)al)); mPUSHs(newRV_noinc((SV*)at));
