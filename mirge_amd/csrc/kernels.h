@@ -295,7 +295,7 @@ MG_HD KEnt make_kent(const uint64_t* __restrict__ text, uint32_t p) {
     uint64_t hi = bs ? (t1 >> bs) | (t2 << (64 - bs)) : t1;
     // Branch-free on purpose.  Written as `if (s0 < 0) { ...shifts... }` hipcc (ROCm 7.2) emits an EXEC-masked
     // block of 64-bit shifts without a skip branch, and on gfx950 that build returned wrong, run-to-run varying
-    // context words for ~8 % of positions (abtest/kent_check3.hip reproduces it); this form is exact.
+    // context words for ~8 % of positions (tools/repro/exec_masked_shift_repro.hip reproduces it); this form is exact.
     const int sh = s0 < 0 ? (int)(-s0) * 2 : 0;        // 0..32
     const uint64_t carry = sh ? lo >> (64 - sh) : 0ull;
     hi = (hi << sh) | carry;
