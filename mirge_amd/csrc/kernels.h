@@ -28,6 +28,7 @@ struct LibDev {
     const uint64_t* bad;
     const uint32_t* koff;
     const KEnt*     kent;
+    const uint32_t* kbits;       // 1 bit per bucket: non-empty?  (4^kb / 8 bytes: cache-resident where koff is not)
     const uint32_t* ref_start;   // n_refs + 1 text coordinates
     uint32_t n_refs;
     uint32_t T;                  // text length in nt, separators included
@@ -309,6 +310,17 @@ k_kmer_scatter(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* 
     if (p < T) kent[atomicAdd(&cursor[text_kmer(text, p, kb)], 1u)] = make_kent(text, p);
 }
 
+// bucket occupancy bitmap from the histogram: most exact-length lookups of reads that do not belong to
+// a library end in an empty bucket, and this answers them from a structure 32x smaller than koff
+__global__ void __launch_bounds__(256)
+k_bucket_bits(const uint32_t* __restrict__ hist, uint64_t nb, uint32_t* kbits) {
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w * 32 >= nb) return;
+    uint32_t bits = 0;
+    for (int j = 0; j < 32; ++j) { uint64_t b = w * 32 + j; if (b < nb && hist[b]) bits |= 1u << j; }
+    kbits[w] = bits;
+}
+
 // exclusive scan of uint32, three kernels: per-chunk sums, scan of the sums (one block), apply.
 constexpr int SCAN_CHUNK = 4096;   // 256 threads x 16
 __global__ void __launch_bounds__(256)
@@ -555,11 +567,16 @@ MG_HD int cand_check(const LibDev& L, const PieceAl& A, const KEnt& e, const Rou
 }
 
 // both ends of a bucket range with one 8-byte load when they are neighbours
-MG_HD void koff_range(const uint32_t* __restrict__ koff, uint64_t b0, uint64_t b1, uint32_t& lo, uint32_t& hi) {
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
-    u32x2 v = *reinterpret_cast<const u32x2*>(koff + b0);
-    lo = v.x; hi = v.y;
-    if (b1 != b0 + 1) hi = koff[b1];
+MG_HD void koff_range(const LibDev& L, uint64_t b0, uint64_t b1, uint32_t& lo, uint32_t& hi) {
+    lo = 0; hi = 0;
+    if (b1 == b0 + 1) {
+        if (!((L.kbits[b0 >> 5] >> (b0 & 31)) & 1)) return;          // empty bucket
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+        u32x2 v = *reinterpret_cast<const u32x2*>(L.koff + b0);
+        lo = v.x; hi = v.y;
+    } else {
+        lo = L.koff[b0]; hi = L.koff[b1];
+    }
 }
 
 // Serial form of the matcher (one read, all candidates in turn): the definition the kernel below
@@ -583,7 +600,7 @@ __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, 
             if (!piece_buckets<SW, HASN>(o, Q.l, L.kb, fw, piece_cut(Q.span, p, np), piece_cut(Q.span, p + 1, np), qs, b0, b1)) continue;
             PieceAl A;
             piece_align<SW, HASN>(o, S, qs, fw, 0u, A);
-            koff_range(L.koff, b0, b1, A.lo, A.hi);
+            koff_range(L, b0, b1, A.lo, A.hi);
             for (uint32_t c = A.lo; c < A.hi; ++c) {
                 int sm, tm; uint32_t w;
                 int r = cand_check<SW>(L, A, L.kent[c], P, sm, tm, w);
@@ -647,23 +664,34 @@ __device__ __forceinline__ void finish_on_text(const uint64_t* __restrict__ ukey
 template <int KW, int RN>
 __global__ void __launch_bounds__(MB)
 k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref,
-              uint8_t* ann_amb, LibDev L, RoundDev P, int thr, unsigned long long* stats) {
+              uint8_t* ann_amb, LibDev L, RoundDev P, int thr, unsigned long long* stats,
+              const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_n,
+              uint32_t* next_list, unsigned long long* next_n) {
+    // list (nullable) = the uniques no earlier round annotated, as left by the previous round's launch;
+    // next_list (nullable) receives this round's survivors.  Dense lists keep the lanes busy in the
+    // later rounds, where most of the table is already annotated.
     constexpr int SW = KeyTraits<KW>::SW;
     constexpr bool HASN = KeyTraits<KW>::HASN;
     __shared__ unsigned long long s_best[3 * MB];
     __shared__ PieceAl s_queue[QCAP];
-    __shared__ uint32_t s_qn, s_next;
+    __shared__ uint32_t s_u[MB];
+    __shared__ uint32_t s_qn, s_next, s_wcnt[MB / 64], s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t u0 = blockIdx.x * MB, u = u0 + tid;
+    const uint32_t n = list ? (uint32_t)*list_n : U;
+    if (blockIdx.x * MB >= n) return;
+    const uint32_t i = blockIdx.x * MB + tid;
+    const uint32_t u = i < n ? (list ? list[i] : i) : EMPTY;
+    s_u[tid] = u;
     bool active = false;
     uint64_t k[KW];
-    if (u < U && ann_round[u] == 0) {
+    if (u != EMPTY && (list || ann_round[u] == 0)) {
 #pragma unroll
         for (int w = 0; w < KW; ++w) k[w] = ukeys[(uint64_t)u * KW + w];
         int len = key_len<KW>(k);
         active = !(P.len_lt && !(len < P.len_lt)) && !(P.len_gt && !(len > P.len_gt));
     }
-    if (!__syncthreads_or(active)) return;
+    const bool listed = u != EMPTY && (list || ann_round[u] == 0);
+    if (!__syncthreads_or(active) && !next_list) return;
     s_best[tid] = 0; s_best[MB + tid] = 0; s_best[2 * MB + tid] = 0;
     if (tid == 0) { s_qn = 0; s_next = 0; }
     __syncthreads();
@@ -688,7 +716,7 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
             int qs = 0; uint64_t b0 = 0, b1 = 0;
             A[f].lo = 0; A[f].hi = 0;
             if (S[f].ok && piece_buckets<SW, HASN>(Q.q[f], Q.l, L.kb, f, ps, pe, qs, b0, b1)) {
-                koff_range(L.koff, b0, b1, A[f].lo, A[f].hi);
+                koff_range(L, b0, b1, A[f].lo, A[f].hi);
                 piece_align<SW, HASN>(Q.q[f], S[f], qs, f, tid, A[f]);
             }
         }
@@ -722,7 +750,7 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
             int sm, tm; uint32_t w;
             int r = cand_check<SW>(L, A, L.kent[c], P, sm, tm, w);
             if (r == 1) record_hit(s_best, owner, sm, tm, w, f);
-            else if (r == 2) finish_on_text<KW>(ukeys, u0 + owner, L, P, f, w, s_best, owner);
+            else if (r == 2) finish_on_text<KW>(ukeys, s_u[owner], L, P, f, w, s_best, owner);
         }
     }
     __syncthreads();
@@ -742,8 +770,23 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     unsigned long long am = __ballot(active), hm = __ballot(hit);
     if (lane == 0) {
         uint32_t slot = (blockIdx.x * 4 + (tid >> 6)) & (STAT_SLOTS - 1);
-        atomicAdd(&stats[(size_t)slot * 8], (unsigned long long)__popcll(am));
+        if (am) atomicAdd(&stats[(size_t)slot * 8], (unsigned long long)__popcll(am));
         if (hm) atomicAdd(&stats[(size_t)(STAT_SLOTS + slot) * 8], (unsigned long long)__popcll(hm));
+    }
+    // survivors -> next round's list (one atomic per block)
+    if (next_list) {
+        const bool surv = listed && !hit;
+        const unsigned long long sm_ = __ballot(surv);
+        if (lane == 0) s_wcnt[tid >> 6] = (uint32_t)__popcll(sm_);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int w = 0; w < MB / 64; ++w) { uint32_t c = s_wcnt[w]; s_wcnt[w] = tot; tot += c; }
+            s_base = tot ? (uint32_t)atomicAdd(next_n, (unsigned long long)tot) : 0u;
+        }
+        __syncthreads();
+        if (surv) next_list[s_base + s_wcnt[tid >> 6] + (uint32_t)__popcll(sm_ & ((1ull << lane) - 1))] = u;
     }
 }
 

@@ -48,15 +48,15 @@ struct Lib {
     std::vector<uint32_t> ref_start;     // n + 1
     uint64_t T = 0;
     int kb = 0;
-    DevBuf text, bad, koff, kent, dref;
+    DevBuf text, bad, koff, kent, kbits, dref;
     LibDev dev() const {
         LibDev L;
         L.text = text.as<uint64_t>(); L.bad = bad.as<uint64_t>(); L.koff = koff.as<uint32_t>();
-        L.kent = kent.as<KEnt>(); L.ref_start = dref.as<uint32_t>();
+        L.kent = kent.as<KEnt>(); L.kbits = kbits.as<uint32_t>(); L.ref_start = dref.as<uint32_t>();
         L.n_refs = (uint32_t)names.size(); L.T = (uint32_t)T; L.kb = kb;
         return L;
     }
-    void release() { text.release(); bad.release(); koff.release(); kent.release(); dref.release(); loaded = false; }
+    void release() { text.release(); bad.release(); koff.release(); kent.release(); kbits.release(); dref.release(); loaded = false; }
 };
 
 constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
@@ -71,9 +71,10 @@ struct Class {
     DevBuf ukeys, coo_g, coo_c;
     DevBuf gslots; uint64_t gcap = 0; bool gvalid = false;     // cross-sample table, built lazily
     DevBuf ann_round, ann_ref, ann_amb;
+    DevBuf act[2], act_n;                       // ping-pong lists of still-unannotated uniques + their lengths
     std::vector<Segment> segs;
     void reset() { U = 0; coo_n = 0; gvalid = false; segs.clear(); }
-    void release() { ukeys.release(); coo_g.release(); coo_c.release(); gslots.release(); ann_round.release(); ann_ref.release(); ann_amb.release(); }
+    void release() { ukeys.release(); coo_g.release(); coo_c.release(); gslots.release(); act[0].release(); act[1].release(); act_n.release(); ann_round.release(); ann_ref.release(); ann_amb.release(); }
 };
 
 struct KTime { const char* name; hipEvent_t a = nullptr, b = nullptr; bool used = false; double ms = 0; uint64_t bytes = 0; };
@@ -87,7 +88,7 @@ struct mirge_ctx {
     std::string err;
     Lib libs[MIRGE_N_LIBS];
     int n_rounds = 5;
-    int coop_thr = 12;                              // candidate lists longer than this are drained by whole waves
+    int coop_thr = 8;                               // candidate lists longer than this are drained by whole waves
     mirge_round rounds[MIRGE_MAX_ROUNDS];
     Class cls[2];                                   // [0] 16-byte keys, [1] 48-byte keys
     // workspaces
@@ -179,10 +180,10 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     L.names = std::move(names);
     L.short_names.clear();
     for (auto& nm : L.names) { size_t e = nm.find_first_of(" \t"); L.short_names.push_back(e == std::string::npos ? nm : nm.substr(0, e)); }
-    int kb = (int)std::lround(std::log2((double)std::max<uint64_t>(T, 16)) / 2.0);
+    int kb = (int)std::lround(std::log2((double)std::max<uint64_t>(T, 16)) / 2.0) + 1;   // ~0.25 random entries per bucket
     L.kb = std::min(14, std::max(4, kb));
-    const char* env = getenv("MIRGE_KB");
-    if (env && atoi(env) >= 2 && atoi(env) <= 15) L.kb = atoi(env);
+    if (const char* env = getenv("MIRGE_KB_BIAS")) L.kb = std::min(14, std::max(4, L.kb + atoi(env)));   // tuning aid
+    if (const char* env = getenv("MIRGE_KB")) { if (atoi(env) >= 2 && atoi(env) <= 15) L.kb = atoi(env); }   // tests
     uint64_t nb = 1ull << (2 * L.kb);
     HIPCHK(c, L.text.ensure(words * 8, false, 0, c->st));
     HIPCHK(c, L.bad.ensure(bwords * 8, false, 0, c->st));
@@ -190,6 +191,8 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     HIPCHK(c, L.koff.ensure((nb + 1) * 4, false, 0, c->st));
     HIPCHK(c, L.kent.ensure(std::max<uint64_t>(T, 1) * sizeof(KEnt), false, 0, c->st));
     HIPCHK(c, c->hist.ensure((nb + 1) * 4, false, 0, c->st));
+    HIPCHK(c, L.kbits.ensure((nb / 32 + 1) * 4, false, 0, c->st));
+    HIPCHK(c, hipMemsetAsync(L.kbits.p, 0, (nb / 32 + 1) * 4, c->st));
     HIPCHK(c, hipMemcpyAsync(L.text.p, text.data(), words * 8, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(L.bad.p, bad.data(), bwords * 8, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(L.dref.p, L.ref_start.data(), (n + 1) * 4, hipMemcpyHostToDevice, c->st));
@@ -197,6 +200,7 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     if (T > 0) {
         uint32_t grid = (uint32_t)((T + 255) / 256);
         hipLaunchKernelGGL(k_kmer_hist, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, c->hist.as<uint32_t>());
+        hipLaunchKernelGGL(k_bucket_bits, dim3((uint32_t)((nb / 32 + 256) / 256)), dim3(256), 0, c->st, c->hist.as<uint32_t>(), nb, L.kbits.as<uint32_t>());
         int rc = scan_exclusive(c, c->hist.as<uint32_t>(), L.koff.as<uint32_t>(), nb + 1);
         if (rc) return rc;
         HIPCHK(c, hipMemcpyAsync(c->hist.p, L.koff.p, nb * 4, hipMemcpyDeviceToDevice, c->st));
@@ -371,7 +375,9 @@ template <int KW, int RN>
 void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, int thr, int r) {
     hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((C.U + MB - 1) / MB)), dim3(MB), 0, c->st,
                        C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
-                       C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats.as<unsigned long long>() + (size_t)r * STAT_WORDS);
+                       C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats.as<unsigned long long>() + (size_t)r * STAT_WORDS,
+                       r == 0 ? (const uint32_t*)nullptr : C.act[(r + 1) & 1].as<uint32_t>(), C.act_n.as<unsigned long long>() + r,
+                       r + 1 < c->n_rounds ? C.act[r & 1].as<uint32_t>() : (uint32_t*)nullptr, C.act_n.as<unsigned long long>() + r + 1);
 }
 
 // the round number is a template parameter only so that every round is its own kernel symbol in a
@@ -431,6 +437,10 @@ int annotate(mirge_ctx* c) {
         HIPCHK(c, hipMemsetAsync(C.ann_round.p, 0, U, c->st));
         HIPCHK(c, hipMemsetAsync(C.ann_ref.p, 0xFF, U * 4, c->st));
         HIPCHK(c, hipMemsetAsync(C.ann_amb.p, 0, U, c->st));
+        HIPCHK(c, C.act[0].ensure(U * 4, false, 0, c->st));
+        HIPCHK(c, C.act[1].ensure(U * 4, false, 0, c->st));
+        HIPCHK(c, C.act_n.ensure((MIRGE_MAX_ROUNDS + 1) * 8, false, 0, c->st));
+        HIPCHK(c, hipMemsetAsync(C.act_n.p, 0, (MIRGE_MAX_ROUNDS + 1) * 8, c->st));
     }
     int M = (int)c->libs[MIRGE_LIB_MIRNA].names.size(), S = c->S;
     size_t qn = std::max<size_t>((size_t)M * S, 1);

@@ -9,9 +9,9 @@ using namespace mg;
 
 struct SimLib {
     std::vector<uint64_t> text, bad;
-    std::vector<uint32_t> koff, ref_start; std::vector<KEnt> kent;
+    std::vector<uint32_t> koff, ref_start, kbits; std::vector<KEnt> kent;
     uint32_t T; int kb;
-    LibDev dev() const { LibDev L; L.text = text.data(); L.bad = bad.data(); L.koff = koff.data(); L.kent = kent.data();
+    LibDev dev() const { LibDev L; L.text = text.data(); L.bad = bad.data(); L.koff = koff.data(); L.kent = kent.data(); L.kbits = kbits.data();
                          L.ref_start = ref_start.data(); L.n_refs = (uint32_t)ref_start.size() - 1; L.T = T; L.kb = kb; return L; }
 };
 
@@ -38,6 +38,8 @@ void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb)
     uint64_t nb = 1ull << (2 * kb);
     S->koff.assign(nb + 1, 0); S->kent.assign(T ? T : 1, KEnt{0, 0, 0, 0});
     for (uint32_t q = 0; q < T; ++q) S->koff[text_kmer(S->text.data(), q, kb) + 1]++;
+    S->kbits.assign(nb / 32 + 1, 0);
+    for (uint64_t b = 0; b < nb; ++b) if (S->koff[b + 1]) S->kbits[b >> 5] |= 1u << (b & 31);
     for (uint64_t b = 0; b < nb; ++b) S->koff[b + 1] += S->koff[b];
     std::vector<uint32_t> cur(S->koff.begin(), S->koff.end() - 1);
     for (uint32_t q = 0; q < T; ++q) S->kent[cur[text_kmer(S->text.data(), q, kb)]++] = make_kent(S->text.data(), q);
