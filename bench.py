@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--reads", type=int, default=20_000_000, help="reads per GPU")
     ap.add_argument("--profile", default="human", choices=["human", "mouse", "medium", "small", "tiny"])
     ap.add_argument("--mixture", default="default", choices=["default", "isomir_rich"])
-    ap.add_argument("--cpu-sample", type=int, default=300_000, help="reads of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=100_000, help="reads of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--chunk", type=int, default=1_000_000)
     args = ap.parse_args()
 
@@ -184,6 +184,17 @@ def main():
         cv = ctx.counts()
         ok = all(np.array_equal(cv[k], res[k]) for k in ("quant", "iscan", "cat", "tuniq", "lenhist"))
         out["parity_on_cpu_sample"] = bool(ok)
+    # size-independent invariants of the full-size run (every read lands in exactly one category / length bin)
+    if world == 1:
+        ctx.reset()
+        ctx.collapse_packed_dev(k16.data_ptr(), n16, k48.data_ptr(), n48, 0)
+        ctx.annotate()
+        cvf = ctx.counts()
+        uid, smp, cnt = ctx.export_counts()
+        out["invariants_full_size"] = bool(int(cvf["cat"].sum()) == N and int(cvf["lenhist"].sum()) == N and
+                                           int(cnt.sum()) == N and int(cvf["tuniq"][0]) == len(cnt) == ctx.n_unique() and
+                                           int(cvf["quant"].sum()) == int(cvf["cat"][0].sum()) and
+                                           sum(s[1] for s in stats) + int((ctx.export_uniques()[2] == 0).sum()) == ctx.n_unique())
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

@@ -180,3 +180,30 @@ def test_partition_invariance(oracle):
             tot = f[:-1].copy() if tot is None else tot + f[:-1]
         flats.append(tot)
     assert np.array_equal(flats[0], flats[1]) and np.array_equal(flats[0], flats[2])
+
+
+def test_policy_cases_on_gpu():
+    """The by-construction known answers of tests/test_policy_known_answers.py, on the device."""
+    from tests.test_policy_known_answers import build_cases
+    lib, cases = build_cases()
+    names = ["ref%d" % i for i in range(len(lib))]
+    with capi.Context(None, 1, 0) as ctx:
+        for l in range(4):
+            ctx.load_library(l, names, seqs=lib)
+        for rnd in sorted({c[2] for c in cases}):
+            sub = [c for c in cases if c[2] == rnd]
+            ctx.set_rounds([(0,) + tuple(rnd[1:])])
+            ctx.reset()
+            ctx.collapse_seqs([c[1] for c in sub], 0)
+            ctx.annotate()
+            got = util.gpu_result_dict(ctx)
+            for what, read, _, ref in sub:
+                assert got[read][1] == ref, what
+
+
+def test_48_sample_batch(oracle):
+    """BASELINE.json configs[4] in small: 48 samples share one unique table, per-sample count vectors."""
+    libs, _ = synth.make_libraries(synth.Profile.small(), 109)
+    samples = [synth.make_reads(libs, 3000, 800 + s, zipf_perm_seed=50 + s % 5) for s in range(48)]
+    res = _compare_with_oracle(oracle, libs, samples)
+    assert res["counts"].shape[1] == 48 and (res["counts"] > 0).sum(axis=1).max() >= 24
