@@ -103,7 +103,7 @@ k_pack(const uint8_t* __restrict__ seqs, uint32_t width, const uint8_t* __restri
 template <int KW, int T, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 k_collapse_local(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* lslots, uint32_t lmask,
-                 uint32_t* cnt, uint32_t* rep_out) {
+                 uint32_t* cnt, uint32_t* cnt0, uint32_t* rep_out) {
     __shared__ uint64_t tk[T * KW];
     __shared__ uint32_t towner[2 * T];
     __shared__ uint32_t tcnt[T];
@@ -137,9 +137,11 @@ k_collapse_local(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* lslots
         }
     }
     __syncthreads();
+    uint32_t mine[PER];
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
         uint32_t idx = tid + e * BLOCK;
+        mine[e] = 0;
         if (idx < nvalid && trep[e] == idx) {
             uint64_t k[KW];
 #pragma unroll
@@ -147,18 +149,30 @@ k_collapse_local(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* lslots
             uint32_t gi = base + idx;
             uint32_t h = (key_hash<KW>(k) >> 7) & lmask;       // different bits than the tile table used
             uint32_t g;
+            bool claimed = false;
             for (;;) {
-                uint32_t o = atomicCAS(&lslots[h], EMPTY, gi);
-                if (o == EMPTY) { g = gi; break; }
+                // look before claiming: a taken slot costs a load, not an atomic (a stale "empty" only
+                // means the compare-and-swap below decides)
+                uint32_t o = __hip_atomic_load(&lslots[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (o == EMPTY) {
+                    o = atomicCAS(&lslots[h], EMPTY, gi);
+                    if (o == EMPTY) { g = gi; claimed = true; break; }
+                }
                 uint64_t ok[KW];
 #pragma unroll
                 for (int w = 0; w < KW; ++w) ok[w] = keys[(uint64_t)o * KW + w];
                 if (key_eq<KW>(ok, k)) { g = o; break; }
                 h = (h + 1) & lmask;
             }
-            atomicAdd(&cnt[g], tcnt[idx]);
+            if (claimed) mine[e] = tcnt[idx];                   // the claimant's own count: a plain store below
+            else atomicAdd(&cnt[g], tcnt[idx]);
             tglob[idx] = g;
         }
+    }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        uint32_t idx = tid + e * BLOCK;
+        if (idx < nvalid) cnt0[base + idx] = mine[e];           // 0 for every read that is not a representative
     }
     if (rep_out) {
         __syncthreads();
@@ -180,7 +194,7 @@ k_collapse_local(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* lslots
 constexpr int EMIT_PER = 8;
 template <int KW>
 __global__ void __launch_bounds__(256)
-k_collapse_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ cnt, uint32_t n,
+k_collapse_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cnt0, uint32_t n,
                 const uint32_t* __restrict__ gslots, uint32_t gmask, uint64_t* ukeys, uint32_t U0,
                 uint32_t* coo_g, uint32_t* coo_c, unsigned long long* ctr, uint32_t* gid_of) {
     __shared__ uint32_t s_scan[256];
@@ -192,7 +206,8 @@ k_collapse_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ 
 #pragma unroll
     for (int e = 0; e < EMIT_PER; ++e) {
         uint32_t i = base + e * 256 + tid;
-        c[e] = i < n ? cnt[i] : 0u;
+        c[e] = 0u;
+        if (i < n) { uint32_t own = cnt0[i]; c[e] = own ? own + cnt[i] : 0u; }     // representative: own count + the duplicates' adds
         g[e] = EMPTY;
         if (c[e] && gslots) {
             uint64_t k[KW];

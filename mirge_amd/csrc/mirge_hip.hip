@@ -92,7 +92,7 @@ struct mirge_ctx {
     mirge_round rounds[MIRGE_MAX_ROUNDS];
     Class cls[2];                                   // [0] 16-byte keys, [1] 48-byte keys
     // workspaces
-    DevBuf lslots, cnt, rep, ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist;
+    DevBuf lslots, cnt, cnt0, rep, ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist;
     DevBuf d_stats, d_quant, d_iscan, d_cat, d_len, d_tu;
     unsigned long long* h_ctr = nullptr;            // pinned, 16 words
     // results
@@ -254,6 +254,7 @@ int collapse_class(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64,
     uint64_t capL = pow2_at_least(2ull * n);
     HIPCHK(c, c->lslots.ensure(capL * 4, false, 0, c->st));
     HIPCHK(c, c->cnt.ensure((size_t)n * 4, false, 0, c->st));
+    HIPCHK(c, c->cnt0.ensure((size_t)n * 4, false, 0, c->st));
     HIPCHK(c, c->ctr.ensure(64, false, 0, c->st));
     HIPCHK(c, C.ukeys.ensure((C.U + n) * KW * 8, true, C.U * KW * 8, c->st));
     HIPCHK(c, C.coo_g.ensure((C.coo_n + n) * 4, true, C.coo_n * 4, c->st));
@@ -276,11 +277,11 @@ int collapse_class(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64,
     constexpr int T = KW == 2 ? 2048 : 512;
     kt_begin(c, tagA);
     hipLaunchKernelGGL((k_collapse_local<KW, T, 256>), dim3((n + T - 1) / T), dim3(256), 0, c->st,
-                       d_keys, n, c->lslots.as<uint32_t>(), (uint32_t)(capL - 1), c->cnt.as<uint32_t>(), (uint32_t*)nullptr);
+                       d_keys, n, c->lslots.as<uint32_t>(), (uint32_t)(capL - 1), c->cnt.as<uint32_t>(), c->cnt0.as<uint32_t>(), (uint32_t*)nullptr);
     kt_end(c, tagA, (uint64_t)n * KW * 8);
     kt_begin(c, tagB);
     hipLaunchKernelGGL((k_collapse_emit<KW>), dim3((n + 256 * EMIT_PER - 1) / (256 * EMIT_PER)), dim3(256), 0, c->st,
-                       d_keys, c->cnt.as<uint32_t>(), n, use_g ? C.gslots.as<uint32_t>() : (const uint32_t*)nullptr,
+                       d_keys, c->cnt.as<uint32_t>(), c->cnt0.as<uint32_t>(), n, use_g ? C.gslots.as<uint32_t>() : (const uint32_t*)nullptr,
                        (uint32_t)(C.gcap ? C.gcap - 1 : 0), C.ukeys.as<uint64_t>(), (uint32_t)C.U,
                        C.coo_g.as<uint32_t>() + C.coo_n, C.coo_c.as<uint32_t>() + C.coo_n,
                        c->ctr.as<unsigned long long>(), (uint32_t*)nullptr);
@@ -376,8 +377,9 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
     hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((C.U + MB - 1) / MB)), dim3(MB), 0, c->st,
                        C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
                        C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats.as<unsigned long long>() + (size_t)r * STAT_WORDS,
-                       r == 0 ? (const uint32_t*)nullptr : C.act[(r + 1) & 1].as<uint32_t>(), C.act_n.as<unsigned long long>() + r,
-                       r + 1 < c->n_rounds ? C.act[r & 1].as<uint32_t>() : (uint32_t*)nullptr, C.act_n.as<unsigned long long>() + r + 1);
+                       r <= 1 ? (const uint32_t*)nullptr : C.act[(r + 1) & 1].as<uint32_t>(), C.act_n.as<unsigned long long>() + r,
+                       (r >= 1 && r + 1 < c->n_rounds) ? C.act[r & 1].as<uint32_t>() : (uint32_t*)nullptr,
+                       C.act_n.as<unsigned long long>() + r + 1);   // round 1 keeps no list: nearly everything survives it
 }
 
 // the round number is a template parameter only so that every round is its own kernel symbol in a
@@ -611,7 +613,7 @@ void mirge_close(mirge_ctx* c) {
     if (c->st) (void)hipStreamSynchronize(c->st);
     for (auto& L : c->libs) L.release();
     for (auto& C : c->cls) C.release();
-    DevBuf* ws[] = {&c->lslots, &c->cnt, &c->rep, &c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
+    DevBuf* ws[] = {&c->lslots, &c->cnt, &c->cnt0, &c->rep, &c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
                     &c->hist, &c->d_stats, &c->d_quant, &c->d_iscan, &c->d_cat, &c->d_len, &c->d_tu};
     for (auto* b : ws) b->release();
     for (auto& k : c->kt) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
