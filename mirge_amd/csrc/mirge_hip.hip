@@ -251,7 +251,7 @@ int collapse_class(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64,
     if (C.U + n64 >= 0xFFFFFFF0ull) return fail(c, MIRGE_E_LIMIT, "more than 2^32 unique sequences");
     uint32_t n = (uint32_t)n64;
     if (n == 0) { C.segs.push_back({sample, C.coo_n, 0}); return MIRGE_OK; }
-    uint64_t capL = pow2_at_least(2ull * n);
+    uint64_t capL = pow2_at_least((uint64_t)n + n / 4);      // load <= 0.8 even if every read is distinct; smaller table = more of it cache-resident
     HIPCHK(c, c->lslots.ensure(capL * 4, false, 0, c->st));
     HIPCHK(c, c->cnt.ensure((size_t)n * 4, false, 0, c->st));
     HIPCHK(c, c->cnt0.ensure((size_t)n * 4, false, 0, c->st));
@@ -274,9 +274,16 @@ int collapse_class(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64,
     HIPCHK(c, hipMemsetAsync(c->lslots.p, 0xFF, capL * 4, c->st));
     HIPCHK(c, hipMemsetAsync(c->cnt.p, 0, (size_t)n * 4, c->st));
     HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 64, c->st));
-    constexpr int T = KW == 2 ? 2048 : 512;
+#ifndef MG_CL_T
+#define MG_CL_T 2048
+#endif
+#ifndef MG_CL_B
+#define MG_CL_B 1024
+#endif
+    constexpr int T = KW == 2 ? MG_CL_T : 512;
+    constexpr int CB = KW == 2 ? MG_CL_B : 256;
     kt_begin(c, tagA);
-    hipLaunchKernelGGL((k_collapse_local<KW, T, 256>), dim3((n + T - 1) / T), dim3(256), 0, c->st,
+    hipLaunchKernelGGL((k_collapse_local<KW, T, CB>), dim3((n + T - 1) / T), dim3(CB), 0, c->st,
                        d_keys, n, c->lslots.as<uint32_t>(), (uint32_t)(capL - 1), c->cnt.as<uint32_t>(), c->cnt0.as<uint32_t>(), (uint32_t*)nullptr);
     kt_end(c, tagA, (uint64_t)n * KW * 8);
     kt_begin(c, tagB);
