@@ -84,6 +84,17 @@ def main():
     del t16, t48, k48_parts
     torch.cuda.synchronize()
 
+    # measured device copy bandwidth of this GPU in this run (report against it as well as the 8 TB/s spec)
+    src = torch.empty(1 << 28, dtype=torch.int32, device="cuda").fill_(1); dst = torch.empty_like(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst.copy_(src); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record(); torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+
     flat_dev = None
 
     def step():
@@ -157,6 +168,7 @@ def main():
                    "parallelism": "shard%d" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "copy_measured": copy_gbs, "frac_of_copy": achieved / copy_gbs,
                      "kernel_ms": dom_ms, "kernel_bytes_alg": dom_bytes},
         "roofline_path": {"bytes_alg_per_read": b_alg / N, "device_ms": dev_ms_avg,
                           "achieved": b_alg / (dev_ms_avg * 1e-3) / 1e9 if dev_ms_avg > 0 else 0.0,

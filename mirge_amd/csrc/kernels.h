@@ -676,8 +676,11 @@ __device__ __forceinline__ void finish_on_text(const uint64_t* __restrict__ ukey
     if (window_ok<SW, HASN>(L, o, S.nsp, S.seedm, S.nN, S.nNseed, (int64_t)w, P, sm, tm)) record_hit(s_best, owner, sm, tm, w, fw);
 }
 
+#ifndef MG_MATCH_WAVES
+#define MG_MATCH_WAVES 6
+#endif
 template <int KW, int RN>
-__global__ void __launch_bounds__(MB)
+__global__ void __launch_bounds__(MB, MG_MATCH_WAVES)
 k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref,
               uint8_t* ann_amb, LibDev L, RoundDev P, int thr, unsigned long long* stats,
               const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_n,
