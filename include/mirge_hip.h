@@ -87,7 +87,15 @@ int32_t     mirge_set_rounds(mirge_ctx*, int32_t n_rounds, const mirge_round* ro
 /* ---- collapse (replaces quantReads, miRge.pl:291-319) --------------------
  * One call per sample, as the reference does; all samples share one table of
  * unique sequences (miRge.pl:99-101). */
+/* The read loop of miRge.pl:299-307 on the device: the file streams into HBM as raw bytes (reader threads ->
+ * pinned ring -> DMA) and is split into records there (four lines each; key = line 2 minus its "\n", nothing
+ * else stripped; a record cut short by the end of the file still counts, with an empty sequence if line 2 is
+ * missing).  n_reads (nullable) receives the number of records. */
 int32_t     mirge_collapse_fastq(mirge_ctx*, const char* trimmed_fastq, int32_t sample, uint64_t* n_reads);
+/* The same for FASTQ text held in host memory / already resident in HBM (d_data 16-byte aligned; no bytes at or
+ * beyond `size` are interpreted, and none beyond the 16-byte unit that holds byte size-1 are touched). */
+int32_t     mirge_collapse_fastq_mem(mirge_ctx*, const char* data, uint64_t size, int32_t sample, uint64_t* n_reads);
+int32_t     mirge_collapse_fastq_dev(mirge_ctx*, const void* d_data, uint64_t size, int32_t sample, uint64_t* n_reads);
 /* Reads from host memory: concatenated ASCII + offs[n+1]. */
 int32_t     mirge_collapse_seqs(mirge_ctx*, const char* seqs, const uint64_t* offs, uint64_t n, int32_t sample);
 /* Reads already resident in HBM as a fixed-width ASCII matrix d_seqs[n][width]

@@ -20,11 +20,14 @@ MAX_READ_LEN = 124
 EXPORTS = [
     "mirge_open", "mirge_close", "mirge_last_error", "mirge_reset", "mirge_load_library_fasta",
     "mirge_load_library_mem", "mirge_lib_size", "mirge_lib_name", "mirge_lib_short_name", "mirge_set_rounds",
-    "mirge_collapse_fastq", "mirge_collapse_seqs", "mirge_collapse_ascii_dev", "mirge_pack_dev",
+    "mirge_collapse_fastq", "mirge_collapse_fastq_mem", "mirge_collapse_fastq_dev", "mirge_collapse_seqs", "mirge_collapse_ascii_dev", "mirge_pack_dev",
     "mirge_collapse_packed_dev", "mirge_annotate", "mirge_round_stats", "mirge_counts", "mirge_counts_flat_len",
     "mirge_counts_flat_get", "mirge_counts_flat_set", "mirge_n_unique", "mirge_unique", "mirge_export_uniques",
     "mirge_n_counts", "mirge_export_counts", "mirge_last_timing", "mirge_kernel_times",
 ]
+
+
+MIRGE_E_ARG, MIRGE_E_IO, MIRGE_E_HIP, MIRGE_E_FORMAT, MIRGE_E_LIMIT = -1, -2, -3, -4, -5    # include/mirge_hip.h
 
 
 class MirgeError(RuntimeError):
@@ -67,6 +70,8 @@ def load():
     L.mirge_lib_short_name.restype = C.c_char_p; L.mirge_lib_short_name.argtypes = [vp, i32, i32]
     L.mirge_set_rounds.argtypes = [vp, i32, vp]
     L.mirge_collapse_fastq.argtypes = [vp, C.c_char_p, i32, C.POINTER(u64)]
+    L.mirge_collapse_fastq_mem.argtypes = [vp, vp, u64, i32, C.POINTER(u64)]
+    L.mirge_collapse_fastq_dev.argtypes = [vp, vp, u64, i32, C.POINTER(u64)]
     L.mirge_collapse_seqs.argtypes = [vp, vp, vp, u64, i32]
     L.mirge_collapse_ascii_dev.argtypes = [vp, vp, u32, vp, u64, i32]
     L.mirge_pack_dev.argtypes = [vp, vp, u32, vp, u64, vp, C.POINTER(u64), vp, C.POINTER(u64)]
@@ -151,6 +156,17 @@ class Context:
     def collapse_fastq(self, path, sample):
         n = C.c_uint64(0)
         self._chk(self.L.mirge_collapse_fastq(self.h, path.encode(), sample, C.byref(n)))
+        return n.value
+
+    def collapse_fastq_mem(self, data: bytes, sample):
+        n = C.c_uint64(0)
+        buf = C.create_string_buffer(data, len(data)) if len(data) else None
+        self._chk(self.L.mirge_collapse_fastq_mem(self.h, C.cast(buf, C.c_void_p) if buf is not None else None, len(data), sample, C.byref(n)))
+        return n.value
+
+    def collapse_fastq_dev(self, d_data, size, sample):
+        n = C.c_uint64(0)
+        self._chk(self.L.mirge_collapse_fastq_dev(self.h, d_data, size, sample, C.byref(n)))
         return n.value
 
     def collapse_seqs(self, reads, sample, lens=None):

@@ -4,13 +4,23 @@
 // that computes launches the kernels of kernels.h and fails if HIP does.
 #include "../../include/mirge_hip.h"
 #include "kernels.h"
+#include "fastq.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 using namespace mg;
 
@@ -93,6 +103,9 @@ struct mirge_ctx {
     Class cls[2];                                   // [0] 16-byte keys, [1] 48-byte keys
     // workspaces
     DevBuf lslots, cnt, cnt0, rep, ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist;
+    DevBuf fq_raw, fq_seg, fq_segb, fq_start;       // FASTQ ingest: raw file bytes, newline counts per segment (+ scanned), record starts
+    uint8_t* fq_pin = nullptr;                      // pinned staging ring for file -> HBM streaming (FQ_SLOTS x FQ_SLOT_BYTES)
+    double ingest_ms = 0;                           // wall time of the last file -> HBM transfer
     DevBuf d_stats, d_quant, d_iscan, d_cat, d_len, d_tu;
     unsigned long long* h_ctr = nullptr;            // pinned, 16 words
     // results
@@ -378,6 +391,145 @@ int collapse_host(mirge_ctx* c, const char* seqs, const uint64_t* offs, uint64_t
     return collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
 }
 
+
+// ---- FASTQ ingest (reference miRge.pl:299-307).  Raw bytes in HBM -> record starts -> keys.
+constexpr int FQ_SLOTS = 8;
+constexpr size_t FQ_SLOT_BYTES = 16u << 20;
+constexpr uint64_t FQ_WINDOW = 1ull << 31;          // bytes per count/scan/index window: newline ordinals of a window fit uint32
+
+// d: 16-byte aligned device pointer to `size` bytes; last = the file's last byte (decides whether the final line is terminated)
+int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t last, int sample, uint64_t* n_reads) {
+    if (sample < 0 || sample >= c->S) return fail(c, MIRGE_E_ARG, "sample index out of range");
+    if ((uintptr_t)d & 15) return fail(c, MIRGE_E_ARG, "FASTQ device buffer must be 16-byte aligned");
+    kt_clear(c, "fastq");
+    HIPCHK(c, c->ctr.ensure(64, false, 0, c->st));
+    uint64_t newlines = 0;
+    std::vector<uint64_t> win_nl;
+    const uint32_t max_seg = (uint32_t)(FQ_WINDOW / FQ_SEG);
+    HIPCHK(c, c->fq_seg.ensure(((size_t)max_seg + 1) * 4, false, 0, c->st));
+    HIPCHK(c, c->fq_segb.ensure(((size_t)max_seg + 1) * 4, false, 0, c->st));
+    // pass 1 per window: newline count (the record count is needed before start[] can be sized)
+    kt_begin(c, "fastq_count");
+    for (uint64_t w0 = 0; w0 < size; w0 += FQ_WINDOW) {
+        uint64_t wsz = std::min(FQ_WINDOW, size - w0);
+        uint32_t nseg = (uint32_t)((wsz + FQ_SEG - 1) / FQ_SEG);
+        HIPCHK(c, hipMemsetAsync(c->fq_seg.as<uint32_t>() + nseg, 0, 4, c->st));
+        hipLaunchKernelGGL(k_fq_count, dim3(nseg), dim3(256), 0, c->st, d + w0, wsz, c->fq_seg.as<uint32_t>());
+        int rc = scan_exclusive(c, c->fq_seg.as<uint32_t>(), c->fq_segb.as<uint32_t>(), (uint64_t)nseg + 1);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->h_ctr + 8, c->fq_segb.as<uint32_t>() + nseg, 4, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        win_nl.push_back((uint32_t)c->h_ctr[8]);
+        newlines += win_nl.back();
+    }
+    kt_end(c, "fastq_count", size);
+    uint64_t lines = newlines + ((size > 0 && last != '\n') ? 1 : 0);
+    uint64_t n = (lines + 3) / 4;
+    if (n_reads) *n_reads = n;
+    if (n >= 0xFFFFFFF0ull) return fail(c, MIRGE_E_LIMIT, "more than 2^32 reads in one collapse call");
+    HIPCHK(c, c->fq_start.ensure(std::max<uint64_t>(n, 1) * 8, false, 0, c->st));
+    HIPCHK(c, c->stage16.ensure(std::max<uint64_t>(n, 1) * 16, false, 0, c->st));
+    HIPCHK(c, c->stage48.ensure(std::max<uint64_t>(n, 1) * 48, false, 0, c->st));
+    HIPCHK(c, hipMemsetAsync(c->fq_start.p, 0xFF, std::max<uint64_t>(n, 1) * 8, c->st));
+    HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 64, c->st));
+    // pass 2 per window: record starts.  Single-window files reuse the scan of pass 1.
+    kt_begin(c, "fastq_index");
+    uint64_t o0 = 0; size_t wi = 0;
+    for (uint64_t w0 = 0; w0 < size; w0 += FQ_WINDOW, ++wi) {
+        uint64_t wsz = std::min(FQ_WINDOW, size - w0);
+        uint32_t nseg = (uint32_t)((wsz + FQ_SEG - 1) / FQ_SEG);
+        if (size > FQ_WINDOW) {
+            HIPCHK(c, hipMemsetAsync(c->fq_seg.as<uint32_t>() + nseg, 0, 4, c->st));
+            hipLaunchKernelGGL(k_fq_count, dim3(nseg), dim3(256), 0, c->st, d + w0, wsz, c->fq_seg.as<uint32_t>());
+            int rc = scan_exclusive(c, c->fq_seg.as<uint32_t>(), c->fq_segb.as<uint32_t>(), (uint64_t)nseg + 1);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_fq_index, dim3(nseg), dim3(256), 0, c->st, d + w0, wsz, w0, o0, c->fq_segb.as<uint32_t>(), c->fq_start.as<uint64_t>());
+        o0 += win_nl[wi];
+    }
+    kt_end(c, "fastq_index", size + n * 8);
+    HIPCHK(c, hipGetLastError());
+    if (n) {
+        kt_begin(c, "fastq_pack");
+        hipLaunchKernelGGL(k_fq_pack, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->st, d, size, c->fq_start.as<uint64_t>(), n,
+                           c->stage16.as<uint64_t>(), c->stage48.as<uint64_t>(), c->ctr.as<unsigned long long>());
+        kt_end(c, "fastq_pack", n * 24 + size / 4);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 32, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (c->h_ctr[2] == 4) return fail(c, MIRGE_E_FORMAT, "read " + std::to_string(c->h_ctr[3]) + " holds a character other than A, C, G, T, N");
+    if (c->h_ctr[2] == 5) return fail(c, MIRGE_E_LIMIT, "read " + std::to_string(c->h_ctr[3]) + " is longer than " + std::to_string(MIRGE_MAX_READ_LEN) + " nt");
+    uint64_t n16 = c->h_ctr[0], n48 = c->h_ctr[1];
+    return collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
+}
+
+// file -> HBM: reader threads pread() slices into a pinned ring, this thread queues one DMA per slice in file order
+int fastq_file_to_hbm(mirge_ctx* c, const char* path, uint64_t* size_out, uint8_t* last_out) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(c, MIRGE_E_IO, std::string("cannot open ") + path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { close(fd); return fail(c, MIRGE_E_IO, std::string(path) + " is not a regular file"); }
+    const uint64_t size = (uint64_t)sb.st_size;
+    *size_out = size; *last_out = '\n';
+    auto t0 = std::chrono::steady_clock::now();
+    hipError_t he = c->fq_raw.ensure(size + 256, false, 0, c->st);
+    if (he != hipSuccess) { close(fd); return fail(c, MIRGE_E_HIP, std::string("FASTQ buffer: ") + hipGetErrorString(he)); }
+    if (size == 0) { close(fd); return MIRGE_OK; }
+    if (!c->fq_pin && hipHostMalloc((void**)&c->fq_pin, FQ_SLOTS * FQ_SLOT_BYTES) != hipSuccess) {
+        close(fd); return fail(c, MIRGE_E_HIP, "cannot allocate the pinned staging ring");
+    }
+    const uint64_t nchunk = (size + FQ_SLOT_BYTES - 1) / FQ_SLOT_BYTES;
+    std::mutex mu; std::condition_variable cv;
+    std::vector<char> filled((size_t)nchunk, 0);
+    uint64_t freed = 0;                              // chunks whose DMA has completed (their slots may be refilled)
+    std::atomic<uint64_t> next{0};
+    bool io_error = false, stop = false;
+    auto reader = [&]() {
+        for (;;) {
+            uint64_t i = next.fetch_add(1);
+            if (i >= nchunk) return;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || i < freed + FQ_SLOTS; }); if (stop) return; }
+            uint8_t* dst = c->fq_pin + (i % FQ_SLOTS) * FQ_SLOT_BYTES;
+            uint64_t off = i * FQ_SLOT_BYTES, want = std::min<uint64_t>(FQ_SLOT_BYTES, size - off), got = 0;
+            while (got < want) {
+                ssize_t r = pread(fd, dst + got, (size_t)(want - got), (off_t)(off + got));
+                if (r <= 0) break;
+                got += (uint64_t)r;
+            }
+            { std::lock_guard<std::mutex> lk(mu); if (got != want) io_error = true; filled[(size_t)i] = 1; }
+            cv.notify_all();
+        }
+    };
+    const int nthr = (int)std::min<uint64_t>(4, nchunk);
+    std::vector<std::thread> thr;
+    for (int t = 0; t < nthr; ++t) thr.emplace_back(reader);
+    hipEvent_t ev[FQ_SLOTS];
+    for (auto& e : ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    int rc = MIRGE_OK;
+    for (uint64_t i = 0; i < nchunk && rc == MIRGE_OK; ++i) {
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[(size_t)i] != 0; }); if (io_error) rc = fail(c, MIRGE_E_IO, std::string("short read on ") + path); }
+        if (rc) break;
+        uint64_t off = i * FQ_SLOT_BYTES, len = std::min<uint64_t>(FQ_SLOT_BYTES, size - off);
+        const uint8_t* src = c->fq_pin + (i % FQ_SLOTS) * FQ_SLOT_BYTES;
+        if (i + 1 == nchunk) *last_out = src[len - 1];
+        hipError_t e = hipMemcpyAsync(c->fq_raw.as<uint8_t>() + off, src, len, hipMemcpyHostToDevice, c->st);
+        if (e == hipSuccess) e = hipEventRecord(ev[i % FQ_SLOTS], c->st);
+        if (e == hipSuccess && i >= 1) e = hipEventSynchronize(ev[(i - 1) % FQ_SLOTS]);      // chunk i is queued behind it: the DMA engine stays busy
+        if (e != hipSuccess) { rc = fail(c, MIRGE_E_HIP, std::string("FASTQ upload: ") + hipGetErrorString(e)); break; }
+        if (i >= 1) { { std::lock_guard<std::mutex> lk(mu); freed = i; } cv.notify_all(); }
+    }
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv.notify_all();
+    for (auto& t : thr) t.join();
+    hipError_t e = hipStreamSynchronize(c->st);
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    close(fd);
+    if (rc == MIRGE_OK && e != hipSuccess) rc = fail(c, MIRGE_E_HIP, std::string("FASTQ upload: ") + hipGetErrorString(e));
+    c->ingest_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
 // ---- cascade + count vectors
 template <int KW, int RN>
 void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, int thr, int r) {
@@ -621,10 +773,11 @@ void mirge_close(mirge_ctx* c) {
     for (auto& L : c->libs) L.release();
     for (auto& C : c->cls) C.release();
     DevBuf* ws[] = {&c->lslots, &c->cnt, &c->cnt0, &c->rep, &c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
-                    &c->hist, &c->d_stats, &c->d_quant, &c->d_iscan, &c->d_cat, &c->d_len, &c->d_tu};
+                    &c->fq_raw, &c->fq_seg, &c->fq_segb, &c->fq_start, &c->hist, &c->d_stats, &c->d_quant, &c->d_iscan, &c->d_cat, &c->d_len, &c->d_tu};
     for (auto* b : ws) b->release();
     for (auto& k : c->kt) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    if (c->fq_pin) (void)hipHostFree(c->fq_pin);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
 }
@@ -689,27 +842,31 @@ int32_t mirge_collapse_seqs(mirge_ctx* c, const char* seqs, const uint64_t* offs
 int32_t mirge_collapse_fastq(mirge_ctx* c, const char* path, int32_t sample, uint64_t* n_reads) {
     if (!c || !path) return MIRGE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    std::string data;
-    int rc = read_file(c, path, data);
+    uint64_t size = 0; uint8_t last = '\n';
+    int rc = fastq_file_to_hbm(c, path, &size, &last);
     if (rc) return rc;
-    // miRge.pl:300-304: records of four lines; the key is line 2 with its "\n" removed
-    std::string seqs; std::vector<uint64_t> offs; offs.push_back(0);
-    size_t i = 0, n = data.size();
-    auto next_line = [&](size_t& b, size_t& e) -> bool {
-        if (i >= n) return false;
-        b = i; e = data.find('\n', i); if (e == std::string::npos) e = n;
-        i = e + 1; return true;
-    };
-    size_t b, e;
-    while (next_line(b, e)) {
-        size_t sb = 0, se = 0;
-        if (next_line(sb, se)) seqs.append(data, sb, se - sb);
-        offs.push_back(seqs.size());
-        size_t x, y; next_line(x, y); next_line(x, y);
+    return collapse_fastq_dev(c, c->fq_raw.as<uint8_t>(), size, last, sample, n_reads);
+}
+
+int32_t mirge_collapse_fastq_mem(mirge_ctx* c, const char* data, uint64_t size, int32_t sample, uint64_t* n_reads) {
+    if (!c || (size && !data)) return c ? fail(c, MIRGE_E_ARG, "null input") : MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->fq_raw.ensure(size + 256, false, 0, c->st));
+    if (size) HIPCHK(c, hipMemcpyAsync(c->fq_raw.p, data, size, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return collapse_fastq_dev(c, c->fq_raw.as<uint8_t>(), size, size ? (uint8_t)data[size - 1] : (uint8_t)'\n', sample, n_reads);
+}
+
+int32_t mirge_collapse_fastq_dev(mirge_ctx* c, const void* d_data, uint64_t size, int32_t sample, uint64_t* n_reads) {
+    if (!c || (size && !d_data)) return c ? fail(c, MIRGE_E_ARG, "null device pointer") : MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint8_t last = '\n';
+    if (size) {
+        HIPCHK(c, hipMemcpyAsync(c->h_ctr + 9, (const uint8_t*)d_data + size - 1, 1, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        last = *(const uint8_t*)(c->h_ctr + 9);
     }
-    uint64_t nr = offs.size() - 1;
-    if (n_reads) *n_reads = nr;
-    return collapse_host(c, seqs.data(), offs.data(), nr, sample);
+    return collapse_fastq_dev(c, (const uint8_t*)d_data, size, last, sample, n_reads);
 }
 
 int32_t mirge_pack_dev(mirge_ctx* c, const void* d_seqs, uint32_t width, const void* d_lens, uint64_t n,

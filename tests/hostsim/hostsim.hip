@@ -3,6 +3,8 @@
 // tricks against the oracle without a GPU.  Test harness only: nothing in the product links it,
 // and the product library has no such entry point.
 #include "../../mirge_amd/csrc/kernels.h"
+#include "../../mirge_amd/csrc/fastq.h"
+#include <algorithm>
 #include <vector>
 #include <cstring>
 using namespace mg;
@@ -70,6 +72,53 @@ int32_t sim_match(void* lib, const uint64_t* key, int32_t kw, const int32_t* rou
     if (kw == 2) ok = match_one<2>(key, S->dev(), P, r, a); else ok = match_one<6>(key, S->dev(), P, r, a);
     *ref = ok ? r : -1; *amb = ok ? (int32_t)a : 0;
     return ok ? 1 : 0;
+}
+
+// FASTQ text -> keys, lane by lane as k_fq_count / k_fq_index / k_fq_pack do it.  data must be 16-byte aligned and
+// readable up to the next multiple of 16.  keys: 6 words per record; kw[i] = 2 or 6.  Returns the record count, or
+// -4 / -5 (the pack pass's error codes).  win = bytes per window (the product uses 2^31; tests pass small values).
+int64_t sim_fastq(const uint8_t* data, uint64_t size, uint64_t win, uint64_t* keys, int32_t* kw, uint64_t cap) {
+    uint64_t newlines = 0;
+    std::vector<std::vector<uint32_t>> lane_cnt;
+    for (uint64_t w0 = 0; w0 < size; w0 += win) {
+        uint64_t wsz = std::min(win, size - w0);
+        uint64_t lanes = (wsz + FQ_TB - 1) / FQ_TB;
+        lane_cnt.emplace_back(lanes, 0u);
+        for (uint64_t l = 0; l < lanes; ++l) {
+            uint32_t w[16]; fq_load64(data + w0, wsz, l * FQ_TB, w);
+            lane_cnt.back()[l] = fq_count64(w, l * FQ_TB, wsz);
+            newlines += lane_cnt.back()[l];
+        }
+    }
+    uint64_t lines = newlines + ((size > 0 && data[size - 1] != '\n') ? 1 : 0);
+    uint64_t n = (lines + 3) / 4;
+    if (n > cap) return -1;
+    std::vector<uint64_t> start(n ? n : 1, FQ_NONE);
+    uint64_t o = 0; size_t wi = 0;
+    for (uint64_t w0 = 0; w0 < size; w0 += win, ++wi) {
+        uint64_t wsz = std::min(win, size - w0);
+        for (uint64_t l = 0; l < lane_cnt[wi].size(); ++l) {
+            uint32_t w[16]; fq_load64(data + w0, wsz, l * FQ_TB, w);
+            if (lane_cnt[wi][l]) fq_index64(w, l * FQ_TB, wsz, w0, o, start.data());
+            o += lane_cnt[wi][l];
+        }
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t sq[4], nm[2]; int len; bool hasN;
+        int rc = fq_pack_read(data, size, start[i] == FQ_NONE ? size : start[i], sq, nm, len, hasN);
+        if (rc) return -rc;
+        uint64_t* k = keys + 6 * i;
+        if (!hasN && len <= 56) { k[0] = sq[0]; k[1] = sq[1] | ((uint64_t)len << 56); kw[i] = 2; }
+        else { k[0] = sq[0]; k[1] = sq[1]; k[2] = sq[2]; k[3] = sq[3] | ((uint64_t)len << 56); k[4] = nm[0]; k[5] = nm[1]; kw[i] = 6; }
+    }
+    return (int64_t)n;
+}
+
+// newlines among the first `size` bytes, counted as k_fq_count does
+uint64_t sim_count_newlines(const uint8_t* data, uint64_t size) {
+    uint64_t c = 0;
+    for (uint64_t off = 0; off < size; off += FQ_TB) { uint32_t w[16]; fq_load64(data, size, off, w); c += fq_count64(w, off, size); }
+    return c;
 }
 
 uint32_t sim_key_hash(const uint64_t* key, int32_t kw) { return kw == 2 ? key_hash<2>(key) : key_hash<6>(key); }
