@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--mixture", default="default", choices=["default", "isomir_rich"])
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="reads of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--chunk", type=int, default=1_000_000)
+    ap.add_argument("--merge-uniques", action="store_true",
+                    help="N > 1: all-to-all of the unique tables by key owner between collapse and cascade (exact trimmed_uniq / "
+                         "per-round unique counts; off by default: the shards of this synthetic workload are independent)")
     ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end leg: FASTQ file -> count vectors (0 = skip)")
     args = ap.parse_args()
 
@@ -105,6 +108,8 @@ def main():
         nonlocal flat_dev
         ctx.reset()
         ctx.collapse_packed_dev(k16.data_ptr(), n16, k48.data_ptr(), n48, 0)
+        if world > 1 and args.merge_uniques:
+            shard.merge_uniques(ctx, dist, torch.device("cuda", local))
         ctx.annotate()
         if world > 1:
             ctx.set_counts_flat(shard.allreduce_flat(ctx.counts_flat(), dist, torch.device("cuda", local)))
@@ -169,7 +174,7 @@ def main():
                    "reads_per_gpu": N, "uniques": int(U), "samples": 1, "mixture": args.mixture,
                    "lib_nt": {nm: int(len(libs[nm].text)) for nm in synth.LIB_NAMES},
                    "round_uniques": [int(s[0]) for s in stats], "round_aligned": [int(s[1]) for s in stats],
-                   "parallelism": "shard%d" % world},
+                   "parallelism": "shard%d%s" % (world, "+merge_uniques" if (world > 1 and args.merge_uniques) else "")},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "copy_measured": copy_gbs, "frac_of_copy": achieved / copy_gbs,

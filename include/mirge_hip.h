@@ -133,6 +133,19 @@ uint64_t    mirge_counts_flat_len(const mirge_ctx*);
 int32_t     mirge_counts_flat_get(mirge_ctx*, uint64_t* out);
 int32_t     mirge_counts_flat_set(mirge_ctx*, const uint64_t* in);
 
+/* Multi-GPU exchange step (no counterpart in the single-process reference).  After the local
+ * collapse, every rank sends each (unique, sample, count) entry to the rank that owns its sequence (a hash of
+ * the key), and annotates only what it owns: sequences present in several shards are then annotated once, and
+ * trimmedUniq (miRge.pl:468) and readsProcessed/readsAligned (miRge.pl:410-413) become sums over ranks like
+ * every other number.  Records: 24 B [key 16 | sample u32 | count u32] for 16-byte keys, 56 B [key 48 | sample |
+ * count] for 48-byte keys.  export_sizes: records per destination rank; export: the records, grouped by
+ * destination in rank order, into caller-provided device buffers (sum(n16) * 24 and sum(n48) * 56 bytes);
+ * import: replaces this context's table by the union of the given records (counts of equal key and sample add).
+ * The all-to-all between export and import is the caller's (mirge_amd/shard.py: torch.distributed, RCCL). */
+int32_t     mirge_shard_export_sizes(mirge_ctx*, int32_t world, uint64_t* n16_per_rank, uint64_t* n48_per_rank);
+int32_t     mirge_shard_export(mirge_ctx*, int32_t world, void* d_rec16, void* d_rec48);
+int32_t     mirge_shard_import(mirge_ctx*, const void* d_rec16, uint64_t n16, const void* d_rec48, uint64_t n48);
+
 /* ---- per-unique results (feeds mapped.csv / unmapped.csv, miRge.pl:702-752,
  *      845-863) -------------------------------------------------------------- */
 uint64_t    mirge_n_unique(const mirge_ctx*);

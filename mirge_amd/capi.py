@@ -20,6 +20,7 @@ MAX_READ_LEN = 124
 EXPORTS = [
     "mirge_open", "mirge_close", "mirge_last_error", "mirge_reset", "mirge_load_library_fasta",
     "mirge_load_library_mem", "mirge_lib_size", "mirge_lib_name", "mirge_lib_short_name", "mirge_set_rounds",
+    "mirge_shard_export_sizes", "mirge_shard_export", "mirge_shard_import",
     "mirge_collapse_fastq", "mirge_collapse_fastq_mem", "mirge_collapse_fastq_dev", "mirge_collapse_seqs", "mirge_collapse_ascii_dev", "mirge_pack_dev",
     "mirge_collapse_packed_dev", "mirge_annotate", "mirge_round_stats", "mirge_counts", "mirge_counts_flat_len",
     "mirge_counts_flat_get", "mirge_counts_flat_set", "mirge_n_unique", "mirge_unique", "mirge_export_uniques",
@@ -70,6 +71,9 @@ def load():
     L.mirge_lib_short_name.restype = C.c_char_p; L.mirge_lib_short_name.argtypes = [vp, i32, i32]
     L.mirge_set_rounds.argtypes = [vp, i32, vp]
     L.mirge_collapse_fastq.argtypes = [vp, C.c_char_p, i32, C.POINTER(u64)]
+    L.mirge_shard_export_sizes.argtypes = [vp, i32, vp, vp]
+    L.mirge_shard_export.argtypes = [vp, i32, vp, vp]
+    L.mirge_shard_import.argtypes = [vp, vp, u64, vp, u64]
     L.mirge_collapse_fastq_mem.argtypes = [vp, vp, u64, i32, C.POINTER(u64)]
     L.mirge_collapse_fastq_dev.argtypes = [vp, vp, u64, i32, C.POINTER(u64)]
     L.mirge_collapse_seqs.argtypes = [vp, vp, vp, u64, i32]
@@ -157,6 +161,18 @@ class Context:
         n = C.c_uint64(0)
         self._chk(self.L.mirge_collapse_fastq(self.h, path.encode(), sample, C.byref(n)))
         return n.value
+
+    # ---- multi-GPU exchange step (include/mirge_hip.h: mirge_shard_*)
+    def shard_export_sizes(self, world):
+        n16 = np.zeros(world, dtype=np.uint64); n48 = np.zeros(world, dtype=np.uint64)
+        self._chk(self.L.mirge_shard_export_sizes(self.h, world, n16.ctypes.data, n48.ctypes.data))
+        return n16, n48
+
+    def shard_export(self, world, d_rec16, d_rec48):
+        self._chk(self.L.mirge_shard_export(self.h, world, d_rec16, d_rec48))
+
+    def shard_import(self, d_rec16, n16, d_rec48, n48):
+        self._chk(self.L.mirge_shard_import(self.h, d_rec16, int(n16), d_rec48, int(n48)))
 
     def collapse_fastq_mem(self, data: bytes, sample):
         n = C.c_uint64(0)

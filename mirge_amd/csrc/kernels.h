@@ -102,8 +102,9 @@ k_pack(const uint8_t* __restrict__ seqs, uint32_t width, const uint8_t* __restri
 // against keys[slot] needs no inter-workgroup hand-off.  cnt[rep read] accumulates the count.
 template <int KW, int T, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
-k_collapse_local(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* lslots, uint32_t lmask,
+k_collapse_local(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ wt, uint32_t n, uint32_t* lslots, uint32_t lmask,
                  uint32_t* cnt, uint32_t* cnt0, uint32_t* rep_out) {
+    // wt (nullable): a count per input key (records merged from other ranks, shard.h); null = one read each
     __shared__ uint64_t tk[T * KW];
     __shared__ uint32_t towner[2 * T];
     __shared__ uint32_t tcnt[T];
@@ -133,7 +134,7 @@ k_collapse_local(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* lslots
                 if (key_eq<KW>(&tk[o * KW], k)) { trep[e] = o; break; }
                 h = (h + 1) & (2u * T - 1);
             }
-            atomicAdd(&tcnt[trep[e]], 1u);
+            atomicAdd(&tcnt[trep[e]], wt ? wt[base + idx] : 1u);
         }
     }
     __syncthreads();

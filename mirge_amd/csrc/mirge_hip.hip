@@ -5,6 +5,7 @@
 #include "../../include/mirge_hip.h"
 #include "kernels.h"
 #include "fastq.h"
+#include "shard.h"
 
 #include <algorithm>
 #include <atomic>
@@ -103,6 +104,8 @@ struct mirge_ctx {
     Class cls[2];                                   // [0] 16-byte keys, [1] 48-byte keys
     // workspaces
     DevBuf lslots, cnt, cnt0, rep, ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist;
+    DevBuf sh_ctr, sh_w[2];                         // multi-GPU exchange: per-owner / per-sample counters, weights of imported records
+    int sh_world = 0; uint64_t sh_n[2][SHARD_MAX_WORLD] = {};
     DevBuf fq_raw, fq_seg, fq_segb, fq_start;       // FASTQ ingest: raw file bytes, newline counts per segment (+ scanned), record starts
     uint8_t* fq_pin = nullptr;                      // pinned staging ring for file -> HBM streaming (FQ_SLOTS x FQ_SLOT_BYTES)
     double ingest_ms = 0;                           // wall time of the last file -> HBM transfer
@@ -259,7 +262,8 @@ int load_fasta(mirge_ctx* c, int lib, const char* path) {
 
 // ---- collapse of one key class
 template <int KW>
-int collapse_class(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64, int sample, const char* tagA, const char* tagB) {
+int collapse_class(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64, int sample, const char* tagA, const char* tagB,
+                   const uint32_t* d_wt = nullptr) {
     if (n64 >= 0xFFFFFFF0ull) return fail(c, MIRGE_E_LIMIT, "more than 2^32 reads in one collapse call");
     if (C.U + n64 >= 0xFFFFFFF0ull) return fail(c, MIRGE_E_LIMIT, "more than 2^32 unique sequences");
     uint32_t n = (uint32_t)n64;
@@ -297,7 +301,7 @@ int collapse_class(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64,
     constexpr int CB = KW == 2 ? MG_CL_B : 256;
     kt_begin(c, tagA);
     hipLaunchKernelGGL((k_collapse_local<KW, T, CB>), dim3((n + T - 1) / T), dim3(CB), 0, c->st,
-                       d_keys, n, c->lslots.as<uint32_t>(), (uint32_t)(capL - 1), c->cnt.as<uint32_t>(), c->cnt0.as<uint32_t>(), (uint32_t*)nullptr);
+                       d_keys, d_wt, n, c->lslots.as<uint32_t>(), (uint32_t)(capL - 1), c->cnt.as<uint32_t>(), c->cnt0.as<uint32_t>(), (uint32_t*)nullptr);
     kt_end(c, tagA, (uint64_t)n * KW * 8);
     kt_begin(c, tagB);
     hipLaunchKernelGGL((k_collapse_emit<KW>), dim3((n + 256 * EMIT_PER - 1) / (256 * EMIT_PER)), dim3(256), 0, c->st,
@@ -527,6 +531,107 @@ int fastq_file_to_hbm(mirge_ctx* c, const char* path, uint64_t* size_out, uint8_
     close(fd);
     if (rc == MIRGE_OK && e != hipSuccess) rc = fail(c, MIRGE_E_HIP, std::string("FASTQ upload: ") + hipGetErrorString(e));
     c->ingest_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+
+// ---- multi-GPU exchange step (shard.h): export this context's (unique, sample, count) entries grouped by owner
+// rank, import the records a rank receives.  The all-to-all itself is the caller's (torch.distributed / RCCL).
+template <int KW>
+void shard_count_class(mirge_ctx* c, Class& C, int world, unsigned long long* d_cnt) {
+    for (auto& sg : C.segs) {
+        if (!sg.count) continue;
+        hipLaunchKernelGGL((k_shard_count<KW>), dim3((uint32_t)((sg.count + 255) / 256)), dim3(256), 0, c->st,
+                           C.coo_g.as<uint32_t>() + sg.start, (uint32_t)sg.count, C.ukeys.as<uint64_t>(), (uint32_t)world, d_cnt);
+    }
+}
+template <int KW>
+void shard_scatter_class(mirge_ctx* c, Class& C, int world, unsigned long long* d_cur, void* d_rec) {
+    for (auto& sg : C.segs) {
+        if (!sg.count) continue;
+        hipLaunchKernelGGL((k_shard_scatter<KW>), dim3((uint32_t)((sg.count + 255) / 256)), dim3(256), 0, c->st,
+                           C.coo_g.as<uint32_t>() + sg.start, C.coo_c.as<uint32_t>() + sg.start, (uint32_t)sg.count, (uint32_t)sg.sample,
+                           C.ukeys.as<uint64_t>(), (uint32_t)world, d_cur, (uint64_t*)d_rec);
+    }
+}
+
+int shard_export_sizes(mirge_ctx* c, int world, uint64_t* n16, uint64_t* n48) {
+    if (world < 1 || world > SHARD_MAX_WORLD) return fail(c, MIRGE_E_ARG, "world size must be between 1 and " + std::to_string(SHARD_MAX_WORLD));
+    HIPCHK(c, c->sh_ctr.ensure(2 * SHARD_MAX_WORLD * 8, false, 0, c->st));
+    HIPCHK(c, hipMemsetAsync(c->sh_ctr.p, 0, 2 * SHARD_MAX_WORLD * 8, c->st));
+    shard_count_class<2>(c, c->cls[0], world, c->sh_ctr.as<unsigned long long>());
+    shard_count_class<6>(c, c->cls[1], world, c->sh_ctr.as<unsigned long long>() + SHARD_MAX_WORLD);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&c->sh_n[0][0], c->sh_ctr.p, 2 * SHARD_MAX_WORLD * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    c->sh_world = world;
+    for (int d = 0; d < world; ++d) { if (n16) n16[d] = c->sh_n[0][d]; if (n48) n48[d] = c->sh_n[1][d]; }
+    return MIRGE_OK;
+}
+
+int shard_export(mirge_ctx* c, int world, void* d16, void* d48) {
+    if (world != c->sh_world) return fail(c, MIRGE_E_ARG, "mirge_shard_export: call mirge_shard_export_sizes with the same world size first");
+    uint64_t cur[2][SHARD_MAX_WORLD] = {};
+    uint64_t tot[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) for (int d = 0; d < world; ++d) { cur[k][d] = tot[k]; tot[k] += c->sh_n[k][d]; }
+    if ((tot[0] && !d16) || (tot[1] && !d48)) return fail(c, MIRGE_E_ARG, "null device buffer");
+    HIPCHK(c, hipMemcpyAsync(c->sh_ctr.p, &cur[0][0], sizeof cur, hipMemcpyHostToDevice, c->st));
+    shard_scatter_class<2>(c, c->cls[0], world, c->sh_ctr.as<unsigned long long>(), d16);
+    shard_scatter_class<6>(c, c->cls[1], world, c->sh_ctr.as<unsigned long long>() + SHARD_MAX_WORLD, d48);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->st));       // cur[] lives on this stack frame
+    return MIRGE_OK;
+}
+
+// records of one class -> keys + weights grouped by sample (in `keys` / `wt`), per-sample counts in cnt_out
+template <int KW>
+int group_records(mirge_ctx* c, const void* d_rec, uint64_t n, DevBuf& keys, DevBuf& wt, std::vector<uint64_t>& cnt_out) {
+    const int S = c->S;
+    cnt_out.assign((size_t)S, 0);
+    if (n == 0) return MIRGE_OK;
+    if (n >= 0xFFFFFFF0ull) return fail(c, MIRGE_E_LIMIT, "more than 2^32 records in one import");
+    HIPCHK(c, c->sh_ctr.ensure(std::max<size_t>((size_t)(S + 1) * 8, 2 * SHARD_MAX_WORLD * 8), false, 0, c->st));
+    HIPCHK(c, hipMemsetAsync(c->sh_ctr.p, 0, (size_t)(S + 1) * 8, c->st));
+    HIPCHK(c, keys.ensure(n * KW * 8, false, 0, c->st));
+    HIPCHK(c, wt.ensure(n * 4, false, 0, c->st));
+    const uint32_t grid = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL((k_rec_count<KW>), dim3(grid), dim3(256), 0, c->st, (const uint64_t*)d_rec, n, (uint32_t)S,
+                       c->sh_ctr.as<unsigned long long>(), c->sh_ctr.as<unsigned long long>() + S);
+    HIPCHK(c, hipGetLastError());
+    std::vector<uint64_t> h((size_t)S + 1);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->sh_ctr.p, (size_t)(S + 1) * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (h[(size_t)S]) return fail(c, MIRGE_E_ARG, std::to_string(h[(size_t)S]) + " imported records name a sample outside this context");
+    std::vector<uint64_t> cur((size_t)S);
+    uint64_t run = 0;
+    for (int s = 0; s < S; ++s) { cnt_out[(size_t)s] = h[(size_t)s]; cur[(size_t)s] = run; run += h[(size_t)s]; }
+    HIPCHK(c, hipMemcpyAsync(c->sh_ctr.p, cur.data(), (size_t)S * 8, hipMemcpyHostToDevice, c->st));
+    hipLaunchKernelGGL((k_rec_scatter<KW>), dim3(grid), dim3(256), 0, c->st, (const uint64_t*)d_rec, n, (uint32_t)S,
+                       c->sh_ctr.as<unsigned long long>(), keys.as<uint64_t>(), wt.as<uint32_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->st));       // cur lives on this stack frame
+    return MIRGE_OK;
+}
+
+int shard_import(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, uint64_t n48) {
+    if (c->S > REC_LDS_S) return fail(c, MIRGE_E_LIMIT, "more than " + std::to_string(REC_LDS_S) + " samples in a sharded run");
+    if ((n16 && !d16) || (n48 && !d48)) return fail(c, MIRGE_E_ARG, "null device buffer");
+    std::vector<uint64_t> c16, c48;
+    int rc = group_records<2>(c, d16, n16, c->stage16, c->sh_w[0], c16);
+    if (!rc) rc = group_records<6>(c, d48, n48, c->stage48, c->sh_w[1], c48);
+    if (rc) return rc;
+    for (auto& C : c->cls) C.reset();
+    c->annotated = false; c->counts_valid = false; c->host_valid = false;
+    kt_clear(c, "collapse");
+    uint64_t o16 = 0, o48 = 0;
+    for (int s = 0; s < c->S && !rc; ++s) {
+        rc = collapse_class<2>(c, c->cls[0], c->stage16.as<uint64_t>() + o16 * 2, c16[(size_t)s], s, "collapse_local16", "collapse_emit16",
+                               c->sh_w[0].as<uint32_t>() + o16);
+        if (!rc) rc = collapse_class<6>(c, c->cls[1], c->stage48.as<uint64_t>() + o48 * 6, c48[(size_t)s], s, "collapse_local48", "collapse_emit48",
+                                        c->sh_w[1].as<uint32_t>() + o48);
+        o16 += c16[(size_t)s]; o48 += c48[(size_t)s];
+    }
+    if (!rc) { HIPCHK(c, hipStreamSynchronize(c->st)); kt_resolve(c); }
     return rc;
 }
 
@@ -773,7 +878,7 @@ void mirge_close(mirge_ctx* c) {
     for (auto& L : c->libs) L.release();
     for (auto& C : c->cls) C.release();
     DevBuf* ws[] = {&c->lslots, &c->cnt, &c->cnt0, &c->rep, &c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
-                    &c->fq_raw, &c->fq_seg, &c->fq_segb, &c->fq_start, &c->hist, &c->d_stats, &c->d_quant, &c->d_iscan, &c->d_cat, &c->d_len, &c->d_tu};
+                    &c->fq_raw, &c->fq_seg, &c->fq_segb, &c->fq_start, &c->sh_ctr, &c->sh_w[0], &c->sh_w[1], &c->hist, &c->d_stats, &c->d_quant, &c->d_iscan, &c->d_cat, &c->d_len, &c->d_tu};
     for (auto* b : ws) b->release();
     for (auto& k : c->kt) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
@@ -867,6 +972,22 @@ int32_t mirge_collapse_fastq_dev(mirge_ctx* c, const void* d_data, uint64_t size
         last = *(const uint8_t*)(c->h_ctr + 9);
     }
     return collapse_fastq_dev(c, (const uint8_t*)d_data, size, last, sample, n_reads);
+}
+
+int32_t mirge_shard_export_sizes(mirge_ctx* c, int32_t world, uint64_t* n16_per_rank, uint64_t* n48_per_rank) {
+    if (!c) return MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return shard_export_sizes(c, world, n16_per_rank, n48_per_rank);
+}
+int32_t mirge_shard_export(mirge_ctx* c, int32_t world, void* d_rec16, void* d_rec48) {
+    if (!c) return MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return shard_export(c, world, d_rec16, d_rec48);
+}
+int32_t mirge_shard_import(mirge_ctx* c, const void* d_rec16, uint64_t n16, const void* d_rec48, uint64_t n48) {
+    if (!c) return MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return shard_import(c, d_rec16, n16, d_rec48, n48);
 }
 
 int32_t mirge_pack_dev(mirge_ctx* c, const void* d_seqs, uint32_t width, const void* d_lens, uint64_t n,

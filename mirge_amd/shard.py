@@ -1,10 +1,12 @@
 """Multi-GPU plumbing: reads shard across ranks (one process per GPU), every rank collapses and
 annotates its own shard, and the count vectors are summed with ONE all-reduce.
 
-The path has no other exchange: annotation is a pure function of the sequence and every graded number
-is a sum over reads.  Not additive across shards, and therefore left out of the reduction's meaning:
-trimmed_uniq (uniques per sample, miRge.pl:468) and the per-round unique counts -- a sequence present
-in two shards is counted in both; merging unique tables across ranks is future work.
+Annotation is a pure function of the sequence and every table number is a sum over reads, so the
+all-reduce alone gives exact count vectors.  Two things are sums over UNIQUES instead: trimmed_uniq
+(miRge.pl:468) and the per-round readsProcessed/readsAligned (miRge.pl:410-413); a sequence present in
+two shards would be counted (and annotated) in both.  merge_uniques() is the optional exchange step that
+makes them exact: one all-to-all of (key, sample, count) records by key owner between collapse and
+cascade, after which every sequence lives on exactly one rank.
 torch.distributed is plumbing here: backend "nccl" (RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
 from __future__ import annotations
@@ -34,3 +36,34 @@ def allreduce_flat(flat: np.ndarray, dist=None, device=None) -> np.ndarray:
         t = t.to(device)
     dist.all_reduce(t)                      # one fused sum: latency-bound (tens of KB), far below the xGMI link rate
     return t.cpu().numpy().view(np.uint64)
+
+
+REC16, REC48 = 24, 56          # bytes per record (include/mirge_hip.h: mirge_shard_export)
+
+
+def merge_uniques(ctx, dist, device):
+    """All-to-all of the local unique tables by key owner.  ctx: capi.Context after its
+    collapse calls; afterwards it holds exactly the sequences this rank owns, with counts summed over all
+    ranks, ready for annotate().  Two collectives: the record counts, then the records (16-byte and
+    48-byte classes in one buffer each)."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n16, n48 = ctx.shard_export_sizes(world)
+    send16 = torch.empty(max(int(n16.sum()) * REC16, 8), dtype=torch.uint8, device=device)
+    send48 = torch.empty(max(int(n48.sum()) * REC48, 8), dtype=torch.uint8, device=device)
+    ctx.shard_export(world, send16.data_ptr(), send48.data_ptr())
+    mine = torch.tensor(np.stack([n16, n48], axis=1).astype(np.int64), device=device)        # [world, 2]: what I send to each rank
+    theirs = torch.empty_like(mine)                                                           # what each rank sends to me
+    dist.all_to_all_single(theirs, mine)
+    r = theirs.cpu().numpy()
+    r16, r48 = r[:, 0], r[:, 1]
+    recv16 = torch.empty(max(int(r16.sum()) * REC16, 8), dtype=torch.uint8, device=device)
+    recv48 = torch.empty(max(int(r48.sum()) * REC48, 8), dtype=torch.uint8, device=device)
+    dist.all_to_all_single(recv16[:int(r16.sum()) * REC16], send16[:int(n16.sum()) * REC16],
+                           output_split_sizes=[int(x) * REC16 for x in r16], input_split_sizes=[int(x) * REC16 for x in n16])
+    dist.all_to_all_single(recv48[:int(r48.sum()) * REC48], send48[:int(n48.sum()) * REC48],
+                           output_split_sizes=[int(x) * REC48 for x in r48], input_split_sizes=[int(x) * REC48 for x in n48])
+    if device is not None and str(device).startswith("cuda"):
+        torch.cuda.synchronize(device)
+    ctx.shard_import(recv16.data_ptr(), int(r16.sum()), recv48.data_ptr(), int(r48.sum()))
+    return int(r16.sum()) + int(r48.sum())

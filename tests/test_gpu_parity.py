@@ -207,3 +207,63 @@ def test_48_sample_batch(oracle):
     samples = [synth.make_reads(libs, 3000, 800 + s, zipf_perm_seed=50 + s % 5) for s in range(48)]
     res = _compare_with_oracle(oracle, libs, samples)
     assert res["counts"].shape[1] == 48 and (res["counts"] > 0).sum(axis=1).max() >= 24
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_unique_table_merge_across_logical_shards(world):
+    """SURVEY.md 8e acceptance: identical results for 1 and N shards, including the numbers that are sums over
+    uniques (trimmed_uniq, per-round processed/aligned).  N logical ranks on one device; the all-to-all of
+    mirge_amd/shard.py is done by hand (slices of the export buffers), the kernels are the real ones."""
+    import torch
+    from mirge_amd import shard
+    libs, _ = synth.make_libraries(synth.Profile.small(), 107)
+    S = 2
+    samples = [synth.make_reads(libs, 30000, 700 + s, zipf_perm_seed=70 + s) for s in range(S)]
+    # a few reads with N / longer than 56 nt so the 48-byte class travels too
+    rng = np.random.default_rng(3)
+    for seqs, lens in samples:
+        for i in rng.integers(0, len(lens), size=200):
+            seqs[i, int(rng.integers(0, lens[i]))] = ord("N")
+    with capi.Context(None, S, 0) as one:
+        util.load_libs_into(one, libs)
+        for s, (seqs, lens) in enumerate(samples):
+            one.collapse_seqs(seqs, s, lens)
+        one.annotate()
+        want = util.gpu_result_dict(one)
+        want_flat = one.counts_flat().copy()
+        want_stats = [one.round_stats(r + 1)[:2] for r in range(5)]
+    ctxs = [capi.Context(None, S, 0) for _ in range(world)]
+    try:
+        sends = []
+        for r, c in enumerate(ctxs):
+            util.load_libs_into(c, libs)
+            for s, (seqs, lens) in enumerate(samples):
+                lo, hi = shard.shard_bounds(len(lens), r, world)
+                c.collapse_seqs(seqs[lo:hi], s, lens[lo:hi])
+            n16, n48 = c.shard_export_sizes(world)
+            b16 = torch.empty(max(int(n16.sum()) * shard.REC16, 8), dtype=torch.uint8, device="cuda")
+            b48 = torch.empty(max(int(n48.sum()) * shard.REC48, 8), dtype=torch.uint8, device="cuda")
+            c.shard_export(world, b16.data_ptr(), b48.data_ptr())
+            o16 = np.concatenate([[0], np.cumsum(n16)]).astype(np.int64) * shard.REC16
+            o48 = np.concatenate([[0], np.cumsum(n48)]).astype(np.int64) * shard.REC48
+            sends.append((b16, o16, b48, o48))
+            assert int(n48.sum()) > 0
+        got, flat, stats = {}, np.zeros_like(want_flat), np.zeros((5, 2), dtype=np.int64)
+        for d, c in enumerate(ctxs):
+            r16 = torch.cat([b16[o16[d]:o16[d + 1]] for b16, o16, _, _ in sends])
+            r48 = torch.cat([b48[o48[d]:o48[d + 1]] for _, _, b48, o48 in sends])
+            torch.cuda.synchronize()
+            c.shard_import(r16.data_ptr() if r16.numel() else 0, r16.numel() // shard.REC16,
+                           r48.data_ptr() if r48.numel() else 0, r48.numel() // shard.REC48)
+            c.annotate()
+            part = util.gpu_result_dict(c)
+            assert not (set(part) & set(got))                 # every sequence lives on exactly one rank
+            got.update(part)
+            flat += c.counts_flat()
+            stats += np.array([c.round_stats(r + 1)[:2] for r in range(5)], dtype=np.int64)
+        assert got == want
+        assert np.array_equal(flat, want_flat)                # trimmed_uniq included
+        assert [tuple(int(x) for x in row) for row in stats] == [tuple(int(x) for x in row) for row in want_stats]
+    finally:
+        for c in ctxs:
+            c.close()
