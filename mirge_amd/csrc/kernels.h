@@ -28,6 +28,7 @@ struct LibDev {
     const uint64_t* bad;
     const uint32_t* koff;
     const KEnt*     kent;
+    const uint64_t* kpre;        // kent order: the middle 32 nt of each entry's context, text[pos-12, pos+20) -- 8-byte pre-filter for long scans
     const uint32_t* kbits;       // 1 bit per bucket: non-empty?  (4^kb / 8 bytes: cache-resident where koff is not)
     const uint32_t* ref_start;   // n_refs + 1 text coordinates
     uint32_t n_refs;
@@ -320,10 +321,17 @@ MG_HD KEnt make_kent(const uint64_t* __restrict__ text, uint32_t p) {
     KEnt e; e.pos = p; e.c0 = (uint32_t)lo; e.c1 = (uint32_t)(lo >> 32); e.c2 = (uint32_t)hi;
     return e;
 }
+// pre-filter word of an entry: context nt 4 .. 35 (text[pos-12, pos+20)), i.e. bits 8 .. 71 of the 96-bit context
+constexpr int PRE_SKIP = 4;
+MG_HD uint64_t make_kpre(const KEnt& e) { return ((((uint64_t)e.c0 | ((uint64_t)e.c1 << 32)) >> (2 * PRE_SKIP)) | ((uint64_t)e.c2 << (64 - 2 * PRE_SKIP))); }
 __global__ void __launch_bounds__(256)
-k_kmer_scatter(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* cursor, KEnt* kent) {
+k_kmer_scatter(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* cursor, KEnt* kent, uint64_t* kpre) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < T) kent[atomicAdd(&cursor[text_kmer(text, p, kb)], 1u)] = make_kent(text, p);
+    if (p < T) {
+        const KEnt e = make_kent(text, p);
+        const uint32_t at = atomicAdd(&cursor[text_kmer(text, p, kb)], 1u);
+        kent[at] = e; kpre[at] = make_kpre(e);
+    }
 }
 
 // bucket occupancy bitmap from the histogram: most exact-length lookups of reads that do not belong to
@@ -582,6 +590,23 @@ MG_HD int cand_check(const LibDev& L, const PieceAl& A, const KEnt& e, const Rou
     return window_clean<SW>(L, (int64_t)w, (int)l) ? 1 : 0;
 }
 
+// Long candidate lists (range queries of short pieces: ~55 entries per lookup for a 16-nt read in the 1-mismatch
+// rounds, ~280 for a 13-nt isomiR query) are bandwidth-bound on the 16-byte entries, and nearly every candidate
+// already fails on the 32 nt around its position.  They are therefore scanned through kpre (8 bytes per entry);
+// only survivors load the full entry.  PreAl = the prepared piece cut down to the pre-filter window.
+struct PreAl { uint64_t ra, m; int nN; };
+MG_HD PreAl pre_of(const PieceAl& A) {
+    PreAl R;
+    R.ra = (A.ra0 >> (2 * PRE_SKIP)) | ((uint64_t)A.ra1 << (64 - 2 * PRE_SKIP));
+    R.m = (A.m0 >> (2 * PRE_SKIP)) | ((uint64_t)A.m1 << (64 - 2 * PRE_SKIP));
+    R.nN = (int)((A.meta >> 24) & 7);
+    return R;
+}
+MG_HD bool pre_pass(const PreAl& R, uint64_t pv, int maxmm) {
+    uint64_t d = pv ^ R.ra; d = (d | (d >> 1)) & R.m;
+    return R.nN + popc64(d) <= maxmm;
+}
+
 // both ends of a bucket range with one 8-byte load when they are neighbours
 MG_HD void koff_range(const LibDev& L, uint64_t b0, uint64_t b1, uint32_t& lo, uint32_t& hi) {
     lo = 0; hi = 0;
@@ -617,8 +642,11 @@ __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, 
             PieceAl A;
             piece_align<SW, HASN>(o, S, qs, fw, 0u, A);
             koff_range(L, b0, b1, A.lo, A.hi);
+            const bool scan = A.hi - A.lo > 8;                  // as the kernel: long lists go through the pre-filter
+            const PreAl R = pre_of(A);
             for (uint32_t c = A.lo; c < A.hi; ++c) {
                 int sm, tm; uint32_t w;
+                if (scan && !pre_pass(R, L.kpre[c], P.maxmm)) continue;
                 int r = cand_check<SW>(L, A, L.kent[c], P, sm, tm, w);
                 if (r == 2) r = window_ok<SW, HASN>(L, o, S.nsp, S.seedm, S.nN, S.nNseed, (int64_t)w, P, sm, tm) ? 1 : 0;
                 if (r == 1) {
@@ -651,7 +679,10 @@ __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, 
 // is instruction-issue bound (rocprof: SQ_ACTIVE_INST_ANY ~ 90 % of SIMD time), so the inner check
 // is kept to one 16-byte load and ~20 VALU instructions.
 constexpr int MB = 256;
-constexpr int QCAP = 384;                        // LDS queue entries per block; a full queue falls back to the serial loop
+#ifndef MG_QCAP
+#define MG_QCAP 384
+#endif
+constexpr int QCAP = MG_QCAP;                        // LDS queue entries per block; a full queue falls back to the serial loop
 constexpr int STAT_SLOTS = 256;                  // per round: [processed | aligned] x STAT_SLOTS words, 64 B apart
 
 __device__ __forceinline__ void record_hit(unsigned long long* s_best, uint32_t owner, int sm, int tm, uint32_t w, int fw) {
@@ -679,6 +710,9 @@ __device__ __forceinline__ void finish_on_text(const uint64_t* __restrict__ ukey
 
 #ifndef MG_MATCH_WAVES
 #define MG_MATCH_WAVES 6
+#endif
+#ifndef MG_PF
+#define MG_PF 2                                  // queue entries a wave has in flight in phase 2 (4 spills registers: slower)
 #endif
 template <int KW, int RN>
 __global__ void __launch_bounds__(MB, MG_MATCH_WAVES)
@@ -715,6 +749,9 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     if (tid == 0) { s_qn = 0; s_next = 0; }
     __syncthreads();
 
+#ifdef MG_PHASE_PROF
+    const long long t0_ = clock64();
+#endif
     // ---- phase 1
     Query<SW> Q;
     if (!active) {
@@ -755,25 +792,59 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         }
     }
     __syncthreads();
+#ifdef MG_PHASE_PROF
+    const long long t1_ = clock64();
+#endif
 
-    // ---- phase 2: drain the queue, one entry per wave at a time
+    // ---- phase 2: drain the queue.  A wave takes MG_PF entries at a time and issues the first 64 pre-filter loads
+    // of each before it looks at any of them: with one entry (one load) in flight per wave the drain ran at the
+    // pace of memory latency (~3 G entries/s chip-wide), not of bandwidth or issue.
     const uint32_t qn = s_qn < (uint32_t)QCAP ? s_qn : (uint32_t)QCAP;
     for (;;) {
-        uint32_t e = 0;
-        if (lane == 0) e = atomicAdd(&s_next, 1u);
-        e = __shfl(e, 0);
-        if (e >= qn) break;
-        const PieceAl A = s_queue[e];
-        const uint32_t owner = A.meta & 255; const int f = (int)((A.meta >> 8) & 1);
-        for (uint32_t c = A.lo + lane; c < A.hi; c += 64) {
-            int sm, tm; uint32_t w;
-            int r = cand_check<SW>(L, A, L.kent[c], P, sm, tm, w);
-            if (r == 1) record_hit(s_best, owner, sm, tm, w, f);
-            else if (r == 2) finish_on_text<KW>(ukeys, s_u[owner], L, P, f, w, s_best, owner);
+        uint32_t e0 = 0;
+        if (lane == 0) e0 = atomicAdd(&s_next, (uint32_t)MG_PF);
+        e0 = __shfl(e0, 0);
+        if (e0 >= qn) break;
+        PreAl R[MG_PF]; uint64_t pv[MG_PF]; uint32_t lo[MG_PF], hi[MG_PF];
+#pragma unroll
+        for (int j = 0; j < MG_PF; ++j) {
+            const uint32_t e = e0 + j < qn ? e0 + j : qn - 1;       // clamp: a valid entry, ignored below
+            R[j] = pre_of(s_queue[e]);
+            lo[j] = s_queue[e].lo; hi[j] = e0 + j < qn ? s_queue[e].hi : lo[j];
+            const uint32_t c = lo[j] + lane;
+            pv[j] = c < hi[j] ? L.kpre[c] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < MG_PF; ++j) {
+            uint32_t c = lo[j] + lane;
+            bool pass = c < hi[j] && pre_pass(R[j], pv[j], P.maxmm);
+            for (;;) {
+                if (pass) {
+                    const PieceAl A = s_queue[e0 + j];
+                    const uint32_t owner = A.meta & 255; const int f = (int)((A.meta >> 8) & 1);
+                    int sm, tm; uint32_t w;
+                    int r = cand_check<SW>(L, A, L.kent[c], P, sm, tm, w);
+                    if (r == 1) record_hit(s_best, owner, sm, tm, w, f);
+                    else if (r == 2) finish_on_text<KW>(ukeys, s_u[owner], L, P, f, w, s_best, owner);
+                }
+                c += 64;
+                if (!__any(c < hi[j])) break;                   // lists longer than 64: the remaining strides, one load each
+                pass = c < hi[j] && pre_pass(R[j], L.kpre[c < hi[j] ? c : lo[j]], P.maxmm);
+            }
         }
     }
     __syncthreads();
 
+#ifdef MG_PHASE_PROF
+    if (tid == 0) {
+        const long long t2_ = clock64();
+        uint32_t slot = blockIdx.x & (STAT_SLOTS - 1);
+        atomicAdd(&stats[(size_t)slot * 8 + 1], (unsigned long long)(t1_ - t0_));
+        atomicAdd(&stats[(size_t)slot * 8 + 2], (unsigned long long)(t2_ - t1_));
+        atomicAdd(&stats[(size_t)slot * 8 + 3], (unsigned long long)qn);
+        atomicAdd(&stats[(size_t)slot * 8 + 4], 1ull);
+    }
+#endif
     // ---- phase 3
     bool hit = false;
     if (Q.ok) {

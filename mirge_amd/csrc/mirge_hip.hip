@@ -59,15 +59,15 @@ struct Lib {
     std::vector<uint32_t> ref_start;     // n + 1
     uint64_t T = 0;
     int kb = 0;
-    DevBuf text, bad, koff, kent, kbits, dref;
+    DevBuf text, bad, koff, kent, kpre, kbits, dref;
     LibDev dev() const {
         LibDev L;
         L.text = text.as<uint64_t>(); L.bad = bad.as<uint64_t>(); L.koff = koff.as<uint32_t>();
-        L.kent = kent.as<KEnt>(); L.kbits = kbits.as<uint32_t>(); L.ref_start = dref.as<uint32_t>();
+        L.kent = kent.as<KEnt>(); L.kpre = kpre.as<uint64_t>(); L.kbits = kbits.as<uint32_t>(); L.ref_start = dref.as<uint32_t>();
         L.n_refs = (uint32_t)names.size(); L.T = (uint32_t)T; L.kb = kb;
         return L;
     }
-    void release() { text.release(); bad.release(); koff.release(); kent.release(); kbits.release(); dref.release(); loaded = false; }
+    void release() { text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); loaded = false; }
 };
 
 constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
@@ -206,6 +206,7 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     HIPCHK(c, L.dref.ensure((n + 1) * 4, false, 0, c->st));
     HIPCHK(c, L.koff.ensure((nb + 1) * 4, false, 0, c->st));
     HIPCHK(c, L.kent.ensure(std::max<uint64_t>(T, 1) * sizeof(KEnt), false, 0, c->st));
+    HIPCHK(c, L.kpre.ensure(std::max<uint64_t>(T, 1) * 8, false, 0, c->st));
     HIPCHK(c, c->hist.ensure((nb + 1) * 4, false, 0, c->st));
     HIPCHK(c, L.kbits.ensure((nb / 32 + 1) * 4, false, 0, c->st));
     HIPCHK(c, hipMemsetAsync(L.kbits.p, 0, (nb / 32 + 1) * 4, c->st));
@@ -220,7 +221,7 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
         int rc = scan_exclusive(c, c->hist.as<uint32_t>(), L.koff.as<uint32_t>(), nb + 1);
         if (rc) return rc;
         HIPCHK(c, hipMemcpyAsync(c->hist.p, L.koff.p, nb * 4, hipMemcpyDeviceToDevice, c->st));
-        hipLaunchKernelGGL(k_kmer_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, c->hist.as<uint32_t>(), L.kent.as<KEnt>());
+        hipLaunchKernelGGL(k_kmer_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, c->hist.as<uint32_t>(), L.kent.as<KEnt>(), L.kpre.as<uint64_t>());
         HIPCHK(c, hipGetLastError());
     } else {
         HIPCHK(c, hipMemsetAsync(L.koff.p, 0, (nb + 1) * 4, c->st));
@@ -399,13 +400,21 @@ int collapse_host(mirge_ctx* c, const char* seqs, const uint64_t* offs, uint64_t
 // ---- FASTQ ingest (reference miRge.pl:299-307).  Raw bytes in HBM -> record starts -> keys.
 constexpr int FQ_SLOTS = 8;
 constexpr size_t FQ_SLOT_BYTES = 16u << 20;
-constexpr uint64_t FQ_WINDOW = 1ull << 31;          // bytes per count/scan/index window: newline ordinals of a window fit uint32
+constexpr uint64_t FQ_WINDOW_DEFAULT = 1ull << 31;  // bytes per count/scan/index window: newline ordinals of a window fit uint32
+uint64_t fq_window() {                              // MIRGE_FQ_WINDOW: smaller windows, so tests reach the multi-window path with small files
+    if (const char* e = getenv("MIRGE_FQ_WINDOW")) {
+        uint64_t w = strtoull(e, nullptr, 10) / FQ_SEG * FQ_SEG;
+        if (w >= (uint64_t)FQ_SEG && w <= FQ_WINDOW_DEFAULT) return w;
+    }
+    return FQ_WINDOW_DEFAULT;
+}
 
 // d: 16-byte aligned device pointer to `size` bytes; last = the file's last byte (decides whether the final line is terminated)
 int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t last, int sample, uint64_t* n_reads) {
     if (sample < 0 || sample >= c->S) return fail(c, MIRGE_E_ARG, "sample index out of range");
     if ((uintptr_t)d & 15) return fail(c, MIRGE_E_ARG, "FASTQ device buffer must be 16-byte aligned");
     kt_clear(c, "fastq");
+    const uint64_t FQ_WINDOW = fq_window();
     HIPCHK(c, c->ctr.ensure(64, false, 0, c->st));
     uint64_t newlines = 0;
     std::vector<uint64_t> win_nl;
@@ -758,6 +767,14 @@ int annotate(mirge_ctx* c) {
     for (int r = 0; r < c->n_rounds; ++r)
         for (int w = 0; w < 2; ++w)
             for (int sl = 0; sl < STAT_SLOTS; ++sl) hs[2 * r + w] += hraw[(size_t)r * STAT_WORDS + ((size_t)w * STAT_SLOTS + sl) * 8];
+#ifdef MG_PHASE_PROF
+    for (int r = 0; r < c->n_rounds; ++r) {
+        uint64_t a[4] = {0, 0, 0, 0};
+        for (int sl = 0; sl < STAT_SLOTS; ++sl) for (int j = 0; j < 4; ++j) a[j] += hraw[(size_t)r * STAT_WORDS + (size_t)sl * 8 + 1 + j];
+        fprintf(stderr, "[phase] round %d: blocks %llu  phase1 %.0f cyc/block  phase2 %.0f cyc/block  queue %.1f entries/block\n", r + 1,
+                (unsigned long long)a[3], a[3] ? (double)a[0] / a[3] : 0.0, a[3] ? (double)a[1] / a[3] : 0.0, a[3] ? (double)a[2] / a[3] : 0.0);
+    }
+#endif
     for (int r = 0; r < c->n_rounds; ++r) {
         c->stats[r][0] = hs[2 * r]; c->stats[r][1] = hs[2 * r + 1];
         c->round_ms[r] = ktime(c, kRoundNames[r]).ms;

@@ -11,9 +11,9 @@ using namespace mg;
 
 struct SimLib {
     std::vector<uint64_t> text, bad;
-    std::vector<uint32_t> koff, ref_start, kbits; std::vector<KEnt> kent;
+    std::vector<uint32_t> koff, ref_start, kbits; std::vector<KEnt> kent; std::vector<uint64_t> kpre;
     uint32_t T; int kb;
-    LibDev dev() const { LibDev L; L.text = text.data(); L.bad = bad.data(); L.koff = koff.data(); L.kent = kent.data(); L.kbits = kbits.data();
+    LibDev dev() const { LibDev L; L.text = text.data(); L.bad = bad.data(); L.koff = koff.data(); L.kent = kent.data(); L.kpre = kpre.data(); L.kbits = kbits.data();
                          L.ref_start = ref_start.data(); L.n_refs = (uint32_t)ref_start.size() - 1; L.T = T; L.kb = kb; return L; }
 };
 
@@ -45,6 +45,8 @@ void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb)
     for (uint64_t b = 0; b < nb; ++b) S->koff[b + 1] += S->koff[b];
     std::vector<uint32_t> cur(S->koff.begin(), S->koff.end() - 1);
     for (uint32_t q = 0; q < T; ++q) S->kent[cur[text_kmer(S->text.data(), q, kb)]++] = make_kent(S->text.data(), q);
+    S->kpre.assign(S->kent.size(), 0);
+    for (size_t i = 0; i < S->kent.size(); ++i) S->kpre[i] = make_kpre(S->kent[i]);
     return S;
 }
 void sim_lib_free(void* s) { delete (SimLib*)s; }

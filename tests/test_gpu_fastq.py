@@ -97,3 +97,15 @@ def test_two_samples_from_files(ctx, tmp_path):
     wa, wb = want(a), want(b)
     assert got == {k: (wa.get(k, 0), wb.get(k, 0)) for k in set(wa) | set(wb)}
     ctx.reset(1)
+
+
+def test_multi_window_path(ctx, monkeypatch):
+    """Files larger than one 2 GiB window are counted / indexed window by window with the newline ordinal carried
+    over; MIRGE_FQ_WINDOW shrinks the window so a 1 MB file crosses many of them."""
+    rng = np.random.default_rng(9)
+    data = random_fastq(rng, 12000, maxlen=60)
+    assert len(data) > 20 * 32768
+    monkeypatch.setenv("MIRGE_FQ_WINDOW", "32768")
+    ctx.reset()
+    assert ctx.collapse_fastq_mem(data, 0) == len(perl_records(data))
+    assert table(ctx) == want(data)
