@@ -761,31 +761,39 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     query_setup<KW>(k, P, Q);
     Q.ok = Q.ok && active;
     const int np = round_np(P);
-    Strand<SW, HASN> S[2];
+    // The kernel is VALU-issue bound (~1500 instructions per read in this phase before this ordering), and most
+    // lookups end in an empty bucket: so the bucket ranges of both strands are fetched first, and the strand
+    // constants + context layout (the expensive part) are computed only for a piece that has candidates.
+    bool sok[2];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) { strand_setup<SW, HASN>(Q.q[f], f, Q.l, Q.s, P, S[f]); S[f].ok = S[f].ok && Q.ok; }
+    for (int f = 0; f < 2; ++f) {
+        sok[f] = Q.ok;
+        if (HASN) { Strand<SW, HASN> T; strand_setup<SW, HASN>(Q.q[f], f, Q.l, Q.s, P, T); sok[f] = sok[f] && T.ok; }
+    }
     for (int p = 0; p < np; ++p) {
         const int ps = piece_cut(Q.span, p, np), pe = piece_cut(Q.span, p + 1, np);
-        PieceAl A[2];
+        uint32_t lo[2], hi[2]; int qs[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            int qs = 0; uint64_t b0 = 0, b1 = 0;
-            A[f].lo = 0; A[f].hi = 0;
-            if (S[f].ok && piece_buckets<SW, HASN>(Q.q[f], Q.l, L.kb, f, ps, pe, qs, b0, b1)) {
-                koff_range(L, b0, b1, A[f].lo, A[f].hi);
-                piece_align<SW, HASN>(Q.q[f], S[f], qs, f, tid, A[f]);
-            }
+            uint64_t b0 = 0, b1 = 0;
+            lo[f] = 0; hi[f] = 0; qs[f] = 0;
+            if (sok[f] && piece_buckets<SW, HASN>(Q.q[f], Q.l, L.kb, f, ps, pe, qs[f], b0, b1)) koff_range(L, b0, b1, lo[f], hi[f]);
         }
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            const uint32_t cnt = A[f].hi - A[f].lo;
+            const uint32_t cnt = hi[f] - lo[f];
             if (cnt == 0) continue;
+            Strand<SW, HASN> S;
+            strand_setup<SW, HASN>(Q.q[f], f, Q.l, Q.s, P, S);
+            PieceAl A;
+            piece_align<SW, HASN>(Q.q[f], S, qs[f], f, tid, A);
+            A.lo = lo[f]; A.hi = hi[f];
             uint32_t e = QCAP;
             if (cnt > (uint32_t)thr) e = atomicAdd(&s_qn, 1u);
-            if (e < (uint32_t)QCAP) { s_queue[e] = A[f]; continue; }
-            for (uint32_t c = A[f].lo; c < A[f].hi; ++c) {
+            if (e < (uint32_t)QCAP) { s_queue[e] = A; continue; }
+            for (uint32_t c = A.lo; c < A.hi; ++c) {
                 int sm, tm; uint32_t w;
-                int r = cand_check<SW>(L, A[f], L.kent[c], P, sm, tm, w);
+                int r = cand_check<SW>(L, A, L.kent[c], P, sm, tm, w);
                 if (r == 1) record_hit(s_best, tid, sm, tm, w, f);
                 else if (r == 2) finish_on_text<KW>(ukeys, u, L, P, f, w, s_best, tid);
             }

@@ -99,7 +99,9 @@ struct mirge_ctx {
     std::string err;
     Lib libs[MIRGE_N_LIBS];
     int n_rounds = 5;
-    int coop_thr = 8;                               // candidate lists longer than this are drained by whole waves
+    int coop_thr = 4;                               // candidate lists longer than this are drained by whole waves (MIRGE_COOP_THR)
+    int coop_thr3 = 16;                             // the same for rounds cut into >= 3 pieces (-n 2): their many long lists would
+                                                    // overflow the LDS queue, so more of them stay with their thread (MIRGE_COOP_THR3)
     mirge_round rounds[MIRGE_MAX_ROUNDS];
     Class cls[2];                                   // [0] 16-byte keys, [1] 48-byte keys
     // workspaces
@@ -662,7 +664,7 @@ int annotate_class(mirge_ctx* c, Class& C, int r, const mirge_round& R) {
     if (C.U == 0) return MIRGE_OK;
     RoundDev P{R.lib, R.len_lt, R.len_gt, R.trim5, R.trim3, R.seedlen, R.seedmm, R.maxmm};
     LibDev L = c->libs[R.lib].dev();
-    int thr = c->coop_thr;
+    int thr = round_np(P) >= 3 ? c->coop_thr3 : c->coop_thr;
     switch (r) {
         case 0: launch_match<KW, 0>(c, C, P, L, thr, r); break;
         case 1: launch_match<KW, 1>(c, C, P, L, thr, r); break;
@@ -870,6 +872,7 @@ mirge_ctx* mirge_open(const char* species_dir, int32_t n_samples, int32_t device
     c->n_rounds = 5;
     for (int i = 0; i < 5; ++i) c->rounds[i] = def[i];
     if (const char* t = getenv("MIRGE_COOP_THR")) c->coop_thr = std::max(0, atoi(t));
+    if (const char* t = getenv("MIRGE_COOP_THR3")) c->coop_thr3 = std::max(0, atoi(t));
     if (species_dir) {
         static const char* nm[MIRGE_N_LIBS] = {"mirna", "hairpin", "other", "mrna"};
         for (int l = 0; l < MIRGE_N_LIBS; ++l) {
