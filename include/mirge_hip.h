@@ -96,6 +96,18 @@ int32_t     mirge_collapse_fastq(mirge_ctx*, const char* trimmed_fastq, int32_t 
  * beyond `size` are interpreted, and none beyond the 16-byte unit that holds byte size-1 are touched). */
 int32_t     mirge_collapse_fastq_mem(mirge_ctx*, const char* data, uint64_t size, int32_t sample, uint64_t* n_reads);
 int32_t     mirge_collapse_fastq_dev(mirge_ctx*, const void* d_data, uint64_t size, int32_t sample, uint64_t* n_reads);
+/* RAW reads: the trimming step of the reference (trimRaw + the `cutadapt -u` pass, miRge.pl:259-261, 268-289;
+ * trim_file.py:26-68) runs on the device between record splitting and packing: 3' quality trimming (cutoff 10),
+ * 3' adapter removal (error rate 0.12, overlap >= 3) or an unconditional cut, length >= 16 filter, then trim5 / trim3
+ * bases off the ends.  adapter as miRge.pl's --adapter: "none", "illumina", "ion", "+N", or up to four comma-separated
+ * 3' adapter sequences (A/C/G/T, <= 32 nt).  total_reads / trimmed_reads = logHash totalReads / trimmedReads
+ * (miRge.pl:285-288); phred = the value trim_file.py prints (33 or 64).  Raw reads of up to 124 nt.
+ * The quality and adapter algorithms are cutadapt's (third party): parity with it is unpinned, see DESIGN.md. */
+int32_t     mirge_collapse_raw_fastq(mirge_ctx*, const char* raw_fastq, int32_t sample, const char* adapter, int32_t trim5,
+                                     int32_t trim3, uint64_t* total_reads, uint64_t* trimmed_reads, int32_t* phred);
+int32_t     mirge_collapse_raw_fastq_mem(mirge_ctx*, const char* data, uint64_t size, int32_t sample, const char* adapter,
+                                         int32_t trim5, int32_t trim3, uint64_t* total_reads, uint64_t* trimmed_reads,
+                                         int32_t* phred);
 /* Reads from host memory: concatenated ASCII + offs[n+1]. */
 int32_t     mirge_collapse_seqs(mirge_ctx*, const char* seqs, const uint64_t* offs, uint64_t n, int32_t sample);
 /* Reads already resident in HBM as a fixed-width ASCII matrix d_seqs[n][width]

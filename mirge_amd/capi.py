@@ -20,6 +20,7 @@ MAX_READ_LEN = 124
 EXPORTS = [
     "mirge_open", "mirge_close", "mirge_last_error", "mirge_reset", "mirge_load_library_fasta",
     "mirge_load_library_mem", "mirge_lib_size", "mirge_lib_name", "mirge_lib_short_name", "mirge_set_rounds",
+    "mirge_collapse_raw_fastq", "mirge_collapse_raw_fastq_mem",
     "mirge_shard_export_sizes", "mirge_shard_export", "mirge_shard_import",
     "mirge_collapse_fastq", "mirge_collapse_fastq_mem", "mirge_collapse_fastq_dev", "mirge_collapse_seqs", "mirge_collapse_ascii_dev", "mirge_pack_dev",
     "mirge_collapse_packed_dev", "mirge_annotate", "mirge_round_stats", "mirge_counts", "mirge_counts_flat_len",
@@ -71,6 +72,8 @@ def load():
     L.mirge_lib_short_name.restype = C.c_char_p; L.mirge_lib_short_name.argtypes = [vp, i32, i32]
     L.mirge_set_rounds.argtypes = [vp, i32, vp]
     L.mirge_collapse_fastq.argtypes = [vp, C.c_char_p, i32, C.POINTER(u64)]
+    L.mirge_collapse_raw_fastq.argtypes = [vp, C.c_char_p, i32, C.c_char_p, i32, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32)]
+    L.mirge_collapse_raw_fastq_mem.argtypes = [vp, vp, u64, i32, C.c_char_p, i32, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32)]
     L.mirge_shard_export_sizes.argtypes = [vp, i32, vp, vp]
     L.mirge_shard_export.argtypes = [vp, i32, vp, vp]
     L.mirge_shard_import.argtypes = [vp, vp, u64, vp, u64]
@@ -173,6 +176,20 @@ class Context:
 
     def shard_import(self, d_rec16, n16, d_rec48, n48):
         self._chk(self.L.mirge_shard_import(self.h, d_rec16, int(n16), d_rec48, int(n48)))
+
+    def collapse_raw_fastq(self, path, sample, adapter="none", trim5=0, trim3=0):
+        """-> (totalReads, trimmedReads, phred)"""
+        tot, kept, ph = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        self._chk(self.L.mirge_collapse_raw_fastq(self.h, path.encode(), sample, adapter.encode(), trim5, trim3,
+                                                  C.byref(tot), C.byref(kept), C.byref(ph)))
+        return tot.value, kept.value, ph.value
+
+    def collapse_raw_fastq_mem(self, data: bytes, sample, adapter="none", trim5=0, trim3=0):
+        tot, kept, ph = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        buf = C.create_string_buffer(data, len(data)) if len(data) else None
+        self._chk(self.L.mirge_collapse_raw_fastq_mem(self.h, C.cast(buf, C.c_void_p) if buf is not None else None, len(data), sample,
+                                                      adapter.encode(), trim5, trim3, C.byref(tot), C.byref(kept), C.byref(ph)))
+        return tot.value, kept.value, ph.value
 
     def collapse_fastq_mem(self, data: bytes, sample):
         n = C.c_uint64(0)

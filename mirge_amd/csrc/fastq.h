@@ -52,14 +52,18 @@ MG_HD uint32_t fq_count64(const uint32_t (&w)[16], uint64_t off, uint64_t size) 
     return c;
 }
 // walk the newlines of one lane-chunk; o = ordinal (in the file) of its first newline, file_off = file offset of data[0]
-MG_HD void fq_index64(const uint32_t (&w)[16], uint64_t off, uint64_t size, uint64_t file_off, uint64_t o, uint64_t* __restrict__ start) {
+// qstart / qend (nullable, both or none): start and end of every record's quality line (line 4), for the trimming path
+MG_HD void fq_index64(const uint32_t (&w)[16], uint64_t off, uint64_t size, uint64_t file_off, uint64_t o, uint64_t* __restrict__ start,
+                      uint64_t* __restrict__ qstart = nullptr, uint64_t* __restrict__ qend = nullptr) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         uint32_t m = nl_mask32_at(w[j], off + 4 * j, size);
         while (m) {
             int b = __builtin_ctz(m) >> 3;                    // byte index inside the word
             m &= m - 1;
-            if ((o & 3) == 0) start[o >> 2] = file_off + off + 4 * j + b + 1;
+            const uint64_t at = file_off + off + 4 * j + b;
+            if ((o & 3) == 0) start[o >> 2] = at + 1;
+            if (qstart) { if ((o & 3) == 2) qstart[o >> 2] = at + 1; else if ((o & 3) == 3) qend[o >> 2] = at; }
             ++o;
         }
     }
@@ -67,6 +71,9 @@ MG_HD void fq_index64(const uint32_t (&w)[16], uint64_t off, uint64_t size, uint
 
 // One record: bytes data[s ...] up to "\n" or the end of the file -> key words.
 // returns 0 ok, 4 = bad character, 5 = longer than 124 nt.  hasN / len as outputs.
+// CR: a "\r" ends the line as well (raw FASTQ goes through cutadapt's reader, which strips line ends; the trimmed
+// file quantReads opens is only chomp'ed: there a "\r" stays and is rejected as a non-nucleotide character).
+template <bool CR = false>
 MG_HD int fq_pack_read(const uint8_t* __restrict__ data, uint64_t size, uint64_t s,
                        uint64_t (&sq)[4], uint64_t (&nm)[2], int& len, bool& hasN) {
     sq[0] = sq[1] = sq[2] = sq[3] = 0; nm[0] = nm[1] = 0; len = 0; hasN = false;
@@ -84,7 +91,7 @@ MG_HD int fq_pack_read(const uint8_t* __restrict__ data, uint64_t size, uint64_t
         for (int b = 0; b < 8; ++b) {
             const uint8_t ch = (uint8_t)(v >> (8 * b));
             const int pos = it * 8 + b;
-            done = done || (s + (uint64_t)pos >= size) || ch == '\n';
+            done = done || (s + (uint64_t)pos >= size) || ch == '\n' || (CR && ch == '\r');
             const bool take = !done && pos < 124;
             over |= !done && pos >= 124;
             const int code = base_code(ch);
@@ -120,7 +127,7 @@ k_fq_count(const uint8_t* __restrict__ data, uint64_t size, uint32_t* __restrict
 
 __global__ void __launch_bounds__(256)
 k_fq_index(const uint8_t* __restrict__ data, uint64_t size, uint64_t file_off, uint64_t o0,
-           const uint32_t* __restrict__ seg_base, uint64_t* __restrict__ start) {
+           const uint32_t* __restrict__ seg_base, uint64_t* __restrict__ start, uint64_t* __restrict__ qstart, uint64_t* __restrict__ qend) {
     __shared__ uint32_t buf[256];
     uint64_t off = (uint64_t)blockIdx.x * FQ_SEG + (uint64_t)threadIdx.x * FQ_TB;
     uint32_t w[16];
@@ -135,7 +142,7 @@ k_fq_index(const uint8_t* __restrict__ data, uint64_t size, uint64_t file_off, u
         __syncthreads();
     }
     // data/size describe one window of the file that begins at byte file_off and after o0 newlines
-    if (c) fq_index64(w, off, size, file_off, o0 + seg_base[blockIdx.x] + buf[threadIdx.x] - c, start);
+    if (c) fq_index64(w, off, size, file_off, o0 + seg_base[blockIdx.x] + buf[threadIdx.x] - c, start, qstart, qend);
 }
 
 // counters as in k_pack: [0] n16, [1] n48, [2] error code, [3] first offending record

@@ -501,6 +501,18 @@ MG_HD void query_setup(const uint64_t* key, const RoundDev& P, Query<KeyTraits<K
     Q.s = P.seedlen < l ? P.seedlen : l;
     Q.span = round_whole(P) ? l : Q.s;
 }
+// the same without the reverse complement (q[0] is left unset): bucket codes of both strands come from the forward
+// read (piece_buckets_fwd), so the kernel builds the reverse complement only for a piece that has candidates
+template <int KW>
+MG_HD void query_setup_fwd(const uint64_t* key, const RoundDev& P, Query<KeyTraits<KW>::SW>& Q) {
+    key_to_read<KW>(key, P.trim5, P.trim3, Q.q[1]);
+    const int l = Q.q[1].l;
+    Q.l = l; Q.ok = !(l <= 0 || l <= P.seedmm);
+    Q.s = 0; Q.span = 0;
+    if (!Q.ok) return;
+    Q.s = P.seedlen < l ? P.seedlen : l;
+    Q.span = round_whole(P) ? l : Q.s;
+}
 // per-strand constants of the mismatch count
 template <int SW, bool HASN> struct Strand { uint64_t seedm[SW], nsp[SW]; int nN, nNseed; bool ok; };
 template <int SW, bool HASN>
@@ -528,6 +540,22 @@ MG_HD bool piece_buckets(const Oriented<SW>& o, int l, int kb, int fw, int ps, i
     if (HASN && n_in_range<SW>(o, qs, kq)) return false;      // a piece holding a read N is not the exact one
     uint32_t code = kmer_code<SW>(o, qs, kq);
     int sh = 2 * (kb - kq);
+    b0 = (uint64_t)code << sh; b1 = ((uint64_t)code + 1) << sh;
+    return true;
+}
+
+// The same from the FORWARD read for either strand.  The reverse-complement piece starts at l - pe of the reversed
+// read and its first kq nt are the complements of forward nt pe-1, pe-2, ..., pe-kq: read least-significant-first
+// from the forward bits that is already the most-significant-first code, complemented (A=0 C=1 G=2 T=3: comp = ~).
+template <int SW, bool HASN>
+MG_HD bool piece_buckets_fwd(const Oriented<SW>& fwd, int l, int kb, int fw, int ps, int pe, int& qs, uint64_t& b0, uint64_t& b1) {
+    if (fw) return piece_buckets<SW, HASN>(fwd, l, kb, 1, ps, pe, qs, b0, b1);
+    qs = l - pe;
+    const int kq = pe - ps < kb ? pe - ps : kb;
+    if (kq <= 0) return false;
+    if (HASN && n_in_range<SW>(fwd, pe - kq, kq)) return false;
+    const uint32_t code = (uint32_t)(~bits_at<SW>(fwd.s, 2 * (pe - kq)) & ones(2 * kq));
+    const int sh = 2 * (kb - kq);
     b0 = (uint64_t)code << sh; b1 = ((uint64_t)code + 1) << sh;
     return true;
 }
@@ -638,7 +666,7 @@ __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, 
         if (!S.ok) continue;
         for (int p = 0; p < np; ++p) {
             int qs; uint64_t b0, b1;
-            if (!piece_buckets<SW, HASN>(o, Q.l, L.kb, fw, piece_cut(Q.span, p, np), piece_cut(Q.span, p + 1, np), qs, b0, b1)) continue;
+            if (!piece_buckets_fwd<SW, HASN>(Q.q[1], Q.l, L.kb, fw, piece_cut(Q.span, p, np), piece_cut(Q.span, p + 1, np), qs, b0, b1)) continue;
             PieceAl A;
             piece_align<SW, HASN>(o, S, qs, fw, 0u, A);
             koff_range(L, b0, b1, A.lo, A.hi);
@@ -758,7 +786,7 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
 #pragma unroll
         for (int w = 0; w < KW; ++w) k[w] = 0;                 // an empty read: Q.ok comes out false
     }
-    query_setup<KW>(k, P, Q);
+    query_setup_fwd<KW>(k, P, Q);
     Q.ok = Q.ok && active;
     const int np = round_np(P);
     // The kernel is VALU-issue bound (~1500 instructions per read in this phase before this ordering), and most
@@ -767,8 +795,8 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     bool sok[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-        sok[f] = Q.ok;
-        if (HASN) { Strand<SW, HASN> T; strand_setup<SW, HASN>(Q.q[f], f, Q.l, Q.s, P, T); sok[f] = sok[f] && T.ok; }
+        sok[f] = Q.ok;       // (the N counts of a read and of its seed are the same on both strands)
+        if (HASN) { Strand<SW, HASN> T; strand_setup<SW, HASN>(Q.q[1], 1, Q.l, Q.s, P, T); sok[f] = sok[f] && T.ok; }
     }
     for (int p = 0; p < np; ++p) {
         const int ps = piece_cut(Q.span, p, np), pe = piece_cut(Q.span, p + 1, np);
@@ -777,16 +805,18 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         for (int f = 0; f < 2; ++f) {
             uint64_t b0 = 0, b1 = 0;
             lo[f] = 0; hi[f] = 0; qs[f] = 0;
-            if (sok[f] && piece_buckets<SW, HASN>(Q.q[f], Q.l, L.kb, f, ps, pe, qs[f], b0, b1)) koff_range(L, b0, b1, lo[f], hi[f]);
+            if (sok[f] && piece_buckets_fwd<SW, HASN>(Q.q[1], Q.l, L.kb, f, ps, pe, qs[f], b0, b1)) koff_range(L, b0, b1, lo[f], hi[f]);
         }
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             const uint32_t cnt = hi[f] - lo[f];
             if (cnt == 0) continue;
+            Oriented<SW> o = Q.q[1];
+            if (!f) revcomp<SW>(Q.q[1], o);
             Strand<SW, HASN> S;
-            strand_setup<SW, HASN>(Q.q[f], f, Q.l, Q.s, P, S);
+            strand_setup<SW, HASN>(o, f, Q.l, Q.s, P, S);
             PieceAl A;
-            piece_align<SW, HASN>(Q.q[f], S, qs[f], f, tid, A);
+            piece_align<SW, HASN>(o, S, qs[f], f, tid, A);
             A.lo = lo[f]; A.hi = hi[f];
             uint32_t e = QCAP;
             if (cnt > (uint32_t)thr) e = atomicAdd(&s_qn, 1u);

@@ -6,6 +6,7 @@
 #include "kernels.h"
 #include "fastq.h"
 #include "shard.h"
+#include "trim.h"
 
 #include <algorithm>
 #include <atomic>
@@ -108,7 +109,7 @@ struct mirge_ctx {
     DevBuf lslots, cnt, cnt0, rep, ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist;
     DevBuf sh_ctr, sh_w[2];                         // multi-GPU exchange: per-owner / per-sample counters, weights of imported records
     int sh_world = 0; uint64_t sh_n[2][SHARD_MAX_WORLD] = {};
-    DevBuf fq_raw, fq_seg, fq_segb, fq_start;       // FASTQ ingest: raw file bytes, newline counts per segment (+ scanned), record starts
+    DevBuf fq_raw, fq_seg, fq_segb, fq_start, fq_qstart, fq_qend;       // FASTQ ingest: raw file bytes, newline counts per segment (+ scanned), record starts
     uint8_t* fq_pin = nullptr;                      // pinned staging ring for file -> HBM streaming (FQ_SLOTS x FQ_SLOT_BYTES)
     double ingest_ms = 0;                           // wall time of the last file -> HBM transfer
     DevBuf d_stats, d_quant, d_iscan, d_cat, d_len, d_tu;
@@ -411,8 +412,19 @@ uint64_t fq_window() {                              // MIRGE_FQ_WINDOW: smaller 
     return FQ_WINDOW_DEFAULT;
 }
 
-// d: 16-byte aligned device pointer to `size` bytes; last = the file's last byte (decides whether the final line is terminated)
-int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t last, int sample, uint64_t* n_reads) {
+// The trimming step of a raw-FASTQ call (trim.h).  adapter: "none", "illumina", "ion" (miRge.pl:80-86), "+N" / "-N",
+// or up to four comma-separated 3' adapter sequences of <= 32 nt.  base is filled in per file (phred detection).
+struct TrimPlan { bool on = false; TrimDev dev; uint64_t kept = 0; int phred_workers = 33, phred_reported = 33; };
+int make_trim_plan(mirge_ctx* c, const char* adapter, int trim5, int trim3, TrimPlan& tp) {
+    tp.on = true;
+    std::string msg;
+    int rc = trim_dev_from_spec(adapter, trim5, trim3, tp.dev, msg);
+    return rc ? fail(c, rc == -5 ? MIRGE_E_LIMIT : MIRGE_E_ARG, msg) : MIRGE_OK;
+}
+
+// d: 16-byte aligned device pointer to `size` bytes; last = the file's last byte (decides whether the final line is terminated).
+// tp (nullable): the file is RAW reads and goes through the trimming step; null: it is the trimmed file quantReads opens.
+int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t last, int sample, uint64_t* n_reads, TrimPlan* tp = nullptr) {
     if (sample < 0 || sample >= c->S) return fail(c, MIRGE_E_ARG, "sample index out of range");
     if ((uintptr_t)d & 15) return fail(c, MIRGE_E_ARG, "FASTQ device buffer must be 16-byte aligned");
     kt_clear(c, "fastq");
@@ -446,6 +458,14 @@ int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t la
     HIPCHK(c, c->stage16.ensure(std::max<uint64_t>(n, 1) * 16, false, 0, c->st));
     HIPCHK(c, c->stage48.ensure(std::max<uint64_t>(n, 1) * 48, false, 0, c->st));
     HIPCHK(c, hipMemsetAsync(c->fq_start.p, 0xFF, std::max<uint64_t>(n, 1) * 8, c->st));
+    uint64_t *d_qs = nullptr, *d_qe = nullptr;
+    if (tp) {
+        HIPCHK(c, c->fq_qstart.ensure(std::max<uint64_t>(n, 1) * 8, false, 0, c->st));
+        HIPCHK(c, c->fq_qend.ensure(std::max<uint64_t>(n, 1) * 8, false, 0, c->st));
+        HIPCHK(c, hipMemsetAsync(c->fq_qstart.p, 0xFF, std::max<uint64_t>(n, 1) * 8, c->st));
+        HIPCHK(c, hipMemsetAsync(c->fq_qend.p, 0xFF, std::max<uint64_t>(n, 1) * 8, c->st));
+        d_qs = c->fq_qstart.as<uint64_t>(); d_qe = c->fq_qend.as<uint64_t>();
+    }
     HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 64, c->st));
     // pass 2 per window: record starts.  Single-window files reuse the scan of pass 1.
     kt_begin(c, "fastq_index");
@@ -459,20 +479,35 @@ int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t la
             int rc = scan_exclusive(c, c->fq_seg.as<uint32_t>(), c->fq_segb.as<uint32_t>(), (uint64_t)nseg + 1);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_fq_index, dim3(nseg), dim3(256), 0, c->st, d + w0, wsz, w0, o0, c->fq_segb.as<uint32_t>(), c->fq_start.as<uint64_t>());
+        hipLaunchKernelGGL(k_fq_index, dim3(nseg), dim3(256), 0, c->st, d + w0, wsz, w0, o0, c->fq_segb.as<uint32_t>(), c->fq_start.as<uint64_t>(), d_qs, d_qe);
         o0 += win_nl[wi];
     }
     kt_end(c, "fastq_index", size + n * 8);
     HIPCHK(c, hipGetLastError());
-    if (n) {
+    if (n && tp) {
+        // phred base as trim_file.py decides it: the workers use what record 0 says, miRge.pl is told what 1000 records say
+        hipLaunchKernelGGL(k_fq_phred, dim3(4), dim3(256), 0, c->st, d, size, d_qs, d_qe, n, c->ctr.as<unsigned long long>() + 5);
+        HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 64, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        tp->phred_workers = c->h_ctr[5] ? 64 : 33; tp->phred_reported = c->h_ctr[6] ? 64 : 33;
+        tp->dev.base = tp->phred_workers;
+        kt_begin(c, "fastq_trim");
+        hipLaunchKernelGGL(k_fq_trim_pack, dim3((uint32_t)((n + TRIM_BLOCK - 1) / TRIM_BLOCK)), dim3(TRIM_BLOCK), 0, c->st, d, size,
+                           c->fq_start.as<uint64_t>(), d_qs, d_qe, n, tp->dev, c->stage16.as<uint64_t>(), c->stage48.as<uint64_t>(),
+                           c->ctr.as<unsigned long long>());
+        kt_end(c, "fastq_trim", size);
+        HIPCHK(c, hipGetLastError());
+    } else if (n) {
         kt_begin(c, "fastq_pack");
         hipLaunchKernelGGL(k_fq_pack, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->st, d, size, c->fq_start.as<uint64_t>(), n,
                            c->stage16.as<uint64_t>(), c->stage48.as<uint64_t>(), c->ctr.as<unsigned long long>());
         kt_end(c, "fastq_pack", n * 24 + size / 4);
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 32, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 40, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    if (tp) tp->kept = c->h_ctr[4];
+    if (c->h_ctr[2] == 6) return fail(c, MIRGE_E_FORMAT, "record " + std::to_string(c->h_ctr[3]) + ": sequence and quality lines differ in length");
     if (c->h_ctr[2] == 4) return fail(c, MIRGE_E_FORMAT, "read " + std::to_string(c->h_ctr[3]) + " holds a character other than A, C, G, T, N");
     if (c->h_ctr[2] == 5) return fail(c, MIRGE_E_LIMIT, "read " + std::to_string(c->h_ctr[3]) + " is longer than " + std::to_string(MIRGE_MAX_READ_LEN) + " nt");
     uint64_t n16 = c->h_ctr[0], n48 = c->h_ctr[1];
@@ -898,7 +933,7 @@ void mirge_close(mirge_ctx* c) {
     for (auto& L : c->libs) L.release();
     for (auto& C : c->cls) C.release();
     DevBuf* ws[] = {&c->lslots, &c->cnt, &c->cnt0, &c->rep, &c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
-                    &c->fq_raw, &c->fq_seg, &c->fq_segb, &c->fq_start, &c->sh_ctr, &c->sh_w[0], &c->sh_w[1], &c->hist, &c->d_stats, &c->d_quant, &c->d_iscan, &c->d_cat, &c->d_len, &c->d_tu};
+                    &c->fq_raw, &c->fq_seg, &c->fq_segb, &c->fq_start, &c->fq_qstart, &c->fq_qend, &c->sh_ctr, &c->sh_w[0], &c->sh_w[1], &c->hist, &c->d_stats, &c->d_quant, &c->d_iscan, &c->d_cat, &c->d_len, &c->d_tu};
     for (auto* b : ws) b->release();
     for (auto& k : c->kt) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
@@ -992,6 +1027,38 @@ int32_t mirge_collapse_fastq_dev(mirge_ctx* c, const void* d_data, uint64_t size
         last = *(const uint8_t*)(c->h_ctr + 9);
     }
     return collapse_fastq_dev(c, (const uint8_t*)d_data, size, last, sample, n_reads);
+}
+
+int32_t mirge_collapse_raw_fastq(mirge_ctx* c, const char* path, int32_t sample, const char* adapter, int32_t trim5, int32_t trim3,
+                                 uint64_t* total_reads, uint64_t* trimmed_reads, int32_t* phred) {
+    if (!c || !path) return MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    TrimPlan tp;
+    int rc = make_trim_plan(c, adapter, trim5, trim3, tp);
+    if (rc) return rc;
+    uint64_t size = 0; uint8_t last = '\n';
+    rc = fastq_file_to_hbm(c, path, &size, &last);
+    if (rc) return rc;
+    rc = collapse_fastq_dev(c, c->fq_raw.as<uint8_t>(), size, last, sample, total_reads, &tp);
+    if (trimmed_reads) *trimmed_reads = tp.kept;
+    if (phred) *phred = tp.phred_reported;
+    return rc;
+}
+
+int32_t mirge_collapse_raw_fastq_mem(mirge_ctx* c, const char* data, uint64_t size, int32_t sample, const char* adapter, int32_t trim5,
+                                     int32_t trim3, uint64_t* total_reads, uint64_t* trimmed_reads, int32_t* phred) {
+    if (!c || (size && !data)) return c ? fail(c, MIRGE_E_ARG, "null input") : MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    TrimPlan tp;
+    int rc = make_trim_plan(c, adapter, trim5, trim3, tp);
+    if (rc) return rc;
+    HIPCHK(c, c->fq_raw.ensure(size + 256, false, 0, c->st));
+    if (size) HIPCHK(c, hipMemcpyAsync(c->fq_raw.p, data, size, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    rc = collapse_fastq_dev(c, c->fq_raw.as<uint8_t>(), size, size ? (uint8_t)data[size - 1] : (uint8_t)'\n', sample, total_reads, &tp);
+    if (trimmed_reads) *trimmed_reads = tp.kept;
+    if (phred) *phred = tp.phred_reported;
+    return rc;
 }
 
 int32_t mirge_shard_export_sizes(mirge_ctx* c, int32_t world, uint64_t* n16_per_rank, uint64_t* n48_per_rank) {

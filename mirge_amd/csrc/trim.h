@@ -1,0 +1,259 @@
+// trim.h -- read trimming on the device: raw FASTQ records -> trimmed 2-bit keys.
+//
+// Replaces, per record, what the reference runs before quantReads (miRge.pl:259-261, 268-289):
+//   trim_file.py:32      QualityTrimmer(0, 10, base)              BWA-style 3' quality trimming
+//   trim_file.py:36-43   AdapterCutter(3' adapters, e = 0.12) | UnconditionalCutter(+N) | nothing ("none")
+//   trim_file.py:57      keep if len >= 16
+//   miRge.pl:261         cutadapt -u trim5 -u -trim3              (no length filter)
+// PARITY UNPINNED: the algorithms are cutadapt's (third party, absent from the reference, no test vector there); they
+// are restated from its 1.9-1.11 sources -- see oracle/trim_oracle.c, which the tests compare this file with.
+//   quality_trim_index : s accumulates (cutoff - q) from the 3' end, stop = position of the maximum, break at s < 0
+//   Adapter.match_to   : leftmost exact occurrence of the adapter, else Aligner.locate: edit-distance DP of the adapter
+//                        (rows) against the read (columns), alignment free to start anywhere in the read and to end inside
+//                        the adapter at the read's end, Ukkonen band (rows whose cost exceeds k = int(rate * m) are
+//                        dropped), best = most matches then lowest cost among cells with cost <= rows * rate, overlap >= 3
+// One lane per record; the DP column (<= 33 cells of cost | matches | origin) lives in LDS, one word per cell and lane.
+#pragma once
+#include "fastq.h"
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+namespace mg {
+
+constexpr int TRIM_MAX_ADAPTERS = 4, TRIM_MAX_ALEN = 32;
+
+struct TrimDev {
+    int32_t mode;                          // 0 = no adapter step, 1 = 3' adapters, 2 = unconditional cut
+    int32_t uncond;                        // mode 2: > 0 removes first bases, < 0 last bases
+    int32_t n_ad;
+    int32_t alen[TRIM_MAX_ADAPTERS];
+    uint64_t acode[TRIM_MAX_ADAPTERS];     // 2-bit codes, adapter nt i at bits 2i
+    int32_t base;                          // phred base of the quality trimmer
+    int32_t trim5, trim3, min_len, min_overlap;
+    int8_t  maxerr[TRIM_MAX_ALEN + 1];     // [len] = largest cost with (double)cost <= len * rate   (host, in double)
+    int8_t  maxerr2[TRIM_MAX_ALEN + 1];    // [len] = largest cost with !((double)cost / len > rate) (host, in double)
+};
+
+// --adapter as miRge.pl takes it -> TrimDev (host).  0 ok, -1 bad argument, -5 over a limit; msg says what.
+inline int trim_dev_from_spec(const char* adapter, int trim5, int trim3, TrimDev& T, std::string& msg) {
+    memset(&T, 0, sizeof T);
+    std::string a = adapter ? adapter : "none";
+    if (a == "illumina") a = "TGGAATTCTCGGGTGCCAAGGAACTCCAG";       // miRge.pl:81-83
+    else if (a == "ion") a = "+11";                                  // miRge.pl:84-86
+    if (trim5 < 0 || trim3 < 0) { msg = "trim5 / trim3 must not be negative"; return -1; }
+    T.trim5 = trim5; T.trim3 = trim3; T.min_len = 16; T.min_overlap = 3; T.base = 33;
+    const double rate = 0.12;                                        // trim_file.py:34
+    for (int len = 0; len <= TRIM_MAX_ALEN; ++len) {
+        int e = 0; while ((double)(e + 1) <= len * rate) ++e;
+        T.maxerr[len] = (int8_t)e;
+        int e2 = 0; while (len > 0 && !((double)(e2 + 1) / len > rate)) ++e2;
+        T.maxerr2[len] = (int8_t)e2;
+    }
+    if (a == "none" || a.empty()) { T.mode = 0; return 0; }
+    if (a[0] == '+' || a[0] == '-') { T.mode = 2; T.uncond = atoi(a.c_str()); return 0; }
+    T.mode = 1;
+    size_t p = 0;
+    while (p <= a.size()) {
+        size_t e = a.find(',', p); if (e == std::string::npos) e = a.size();
+        std::string one = a.substr(p, e - p);
+        p = e + 1;
+        if (one.empty()) continue;
+        if (T.n_ad >= TRIM_MAX_ADAPTERS) { msg = "more than " + std::to_string(TRIM_MAX_ADAPTERS) + " adapters"; return -5; }
+        if ((int)one.size() > TRIM_MAX_ALEN) { msg = "adapter longer than " + std::to_string(TRIM_MAX_ALEN) + " nt"; return -5; }
+        uint64_t code = 0;
+        for (size_t i = 0; i < one.size(); ++i) {
+            int b = base_code((uint8_t)one[i]);
+            if (b < 0 || b > 3) { msg = "adapter '" + one + "': only plain 3' adapters of A, C, G, T are supported"; return -1; }
+            code |= (uint64_t)b << (2 * i);
+        }
+        T.alen[T.n_ad] = (int32_t)one.size(); T.acode[T.n_ad] = code; ++T.n_ad;
+    }
+    if (!T.n_ad) T.mode = 0;
+    return 0;
+}
+
+MG_HD int code_at(const uint64_t (&sq)[4], int j) { return (int)((pick<4>(sq, j >> 5) >> (2 * (j & 31))) & 3); }
+MG_HD bool isn_at(const uint64_t (&nm)[2], int j) { return ((j < 64 ? nm[0] : nm[1]) >> (j & 63)) & 1; }
+
+// DP cell: cost (bits 24-31) | matches (16-23) | origin (0-15)
+MG_HD uint32_t cell(int cost, int matches, int origin) { return ((uint32_t)cost << 24) | ((uint32_t)matches << 16) | (uint32_t)origin; }
+MG_HD int c_cost(uint32_t c) { return (int)(c >> 24); }
+MG_HD int c_matches(uint32_t c) { return (int)((c >> 16) & 255); }
+MG_HD int c_origin(uint32_t c) { return (int)(c & 0xFFFF); }
+
+// Adapter `ad` against read nts [a, b): true if it matches; rstart (relative to a) and matches out.
+// col: this lane's DP column, cell i at col[i * stride].
+MG_HD bool adapter_match(const TrimDev& T, int ad, const uint64_t (&sq)[4], const uint64_t (&nm)[2], int a, int b,
+                         uint32_t* col, int stride, int& rstart, int& matches_out) {
+    const int m = T.alen[ad], n = b - a;
+    const uint64_t ac = T.acode[ad];
+    // leftmost exact occurrence: rolling 2m-bit window over the read
+    {
+        const uint64_t full = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1);
+        uint64_t h = 0; int nrun = 0;                        // nrun: nts since the last N
+        for (int j = 0; j < n; ++j) {
+            const int c = code_at(sq, a + j);
+            const bool isn = isn_at(nm, a + j);
+            h = ((h >> 2) | ((uint64_t)c << (2 * (m - 1)))) & full;
+            nrun = isn ? 0 : nrun + 1;
+            if (j >= m - 1 && nrun >= m && h == ac) { rstart = j - m + 1; matches_out = m; return true; }
+        }
+    }
+    const int k = T.maxerr[m];
+    for (int i = 0; i <= m; ++i) col[i * stride] = cell(i, 0, 0);
+    int best_matches = 0, best_cost = m + n, best_origin = 0, best_ref_stop = m;
+    int last = m < k + 1 ? m : k + 1;
+    bool done = false;
+    for (int j = 1; j <= n && !done; ++j) {
+        const int cj = code_at(sq, a + j - 1);
+        const bool nj = isn_at(nm, a + j - 1);
+        uint32_t tmp = col[0];
+        uint32_t up = cell(0, 0, j);                          // column[0]: cost 0, origin j
+        col[0] = up;
+        for (int i = 1; i <= last; ++i) {
+            const uint32_t cur = col[i * stride];
+            const bool eq = !nj && (int)((ac >> (2 * (i - 1))) & 3) == cj;
+            uint32_t nw;
+            if (eq) nw = cell(c_cost(tmp), c_matches(tmp) + 1, c_origin(tmp));
+            else {
+                const int cd = c_cost(tmp) + 1, cdel = c_cost(cur) + 1, cins = c_cost(up) + 1;
+                if (cd <= cdel && cd <= cins) nw = cell(cd, c_matches(tmp), c_origin(tmp));
+                else if (cins <= cdel) nw = cell(cins, c_matches(up), c_origin(up));
+                else nw = cell(cdel, c_matches(cur), c_origin(cur));
+            }
+            tmp = cur; up = nw;
+            col[i * stride] = nw;
+        }
+        while (last >= 0 && c_cost(col[last * stride]) > k) --last;
+        if (last < m) ++last;
+        else {
+            const uint32_t c = col[m * stride];
+            const int cost = c_cost(c), matches = c_matches(c);
+            if (m >= T.min_overlap && cost <= T.maxerr[m] && (matches > best_matches || (matches == best_matches && cost < best_cost))) {
+                best_matches = matches; best_cost = cost; best_origin = c_origin(c); best_ref_stop = m;
+                if (cost == 0 && matches == m) done = true;
+            }
+        }
+    }
+    for (int i = m; i >= 0; --i) {
+        const uint32_t c = col[i * stride];
+        const int cost = c_cost(c), matches = c_matches(c);
+        if (i >= T.min_overlap && cost <= T.maxerr[i] && (matches > best_matches || (matches == best_matches && cost < best_cost))) {
+            best_matches = matches; best_cost = cost; best_origin = c_origin(c); best_ref_stop = i;
+        }
+    }
+    if (best_cost == m + n) return false;
+    const int length = best_ref_stop;
+    if (length < T.min_overlap || best_cost > T.maxerr2[length]) return false;
+    rstart = best_origin; matches_out = best_matches;
+    return true;
+}
+
+// quality line [qs, qs + n) -> [start, stop) as cutadapt's quality_trim_index(q, 0, 10, base)
+MG_HD void quality_trim(const uint8_t* __restrict__ data, uint64_t qs, int n, int base, int& start, int& stop) {
+    const uint64_t* d64 = reinterpret_cast<const uint64_t*>(data);
+    uint64_t w = 0, wi = ~0ull;
+    int s = 0, mx = 0;
+    start = 0; stop = n;
+    for (int i = 0; i < n; ++i) {
+        const uint64_t p = qs + (uint64_t)i;
+        if ((p >> 3) != wi) { wi = p >> 3; w = d64[wi]; }
+        s += 0 - ((int)((w >> (8 * (p & 7))) & 255) - base);
+        if (s < 0) break;
+        if (s > mx) { mx = s; start = i + 1; }
+    }
+    s = 0; mx = 0;
+    for (int i = n - 1; i >= 0; --i) {
+        const uint64_t p = qs + (uint64_t)i;
+        if ((p >> 3) != wi) { wi = p >> 3; w = d64[wi]; }
+        s += 10 - ((int)((w >> (8 * (p & 7))) & 255) - base);
+        if (s < 0) break;
+        if (s > mx) { mx = s; stop = i; }
+    }
+    if (start >= stop) { start = 0; stop = 0; }
+}
+
+// One record.  s / qs / qe: offsets of its sequence line, quality line and the end of the quality line.
+// returns 0 = dropped (too short), 1 = kept (key words + len out), or an error code: 4 bad character,
+// 5 longer than 124 nt, 6 sequence and quality lines differ in length.
+MG_HD int trim_record(const uint8_t* __restrict__ data, uint64_t size, uint64_t s, uint64_t qs, uint64_t qe, const TrimDev& T,
+                      uint32_t* col, int stride, uint64_t (&ks)[4], uint64_t (&kn)[2], int& klen) {
+    uint64_t sq[4], nm[2]; int len; bool hasN;
+    int rc = fq_pack_read<true>(data, size, s, sq, nm, len, hasN);
+    if (rc) return rc;
+    if (qe > qs && data[qe - 1] == '\r') --qe;                 // cutadapt's FastqReader strips line ends
+    if ((int)(qe - qs) != len) return 6;
+    int a, b;
+    quality_trim(data, qs, len, T.base, a, b);
+    if (T.mode == 2) {
+        if (T.uncond > 0) a = a + T.uncond < b ? a + T.uncond : b;
+        else if (T.uncond < 0) b = b + T.uncond > a ? b + T.uncond : a;
+    } else if (T.mode == 1) {
+        int best_matches = -1, best_rstart = -1;
+        for (int ad = 0; ad < T.n_ad; ++ad) {
+            int rs = 0, mt = 0;
+            if (adapter_match(T, ad, sq, nm, a, b, col, stride, rs, mt) && mt > best_matches) { best_matches = mt; best_rstart = rs; }
+        }
+        if (best_rstart >= 0) b = a + best_rstart;
+    }
+    if (b - a < T.min_len) return 0;
+    if (T.trim5 > 0) a = a + T.trim5 < b ? a + T.trim5 : b;
+    if (T.trim3 > 0) b = b - T.trim3 > a ? b - T.trim3 : a;
+    klen = b - a;
+    shr<4>(sq, 2 * a, ks); keep_low<4>(ks, 2 * klen);
+    shr<2>(nm, a, kn); keep_low<2>(kn, klen);
+    return 1;
+}
+
+#ifdef __HIPCC__
+constexpr int TRIM_BLOCK = 256;
+// counters: [0] n16, [1] n48, [2] error code, [3] first offending record, [4] records kept
+__global__ void __launch_bounds__(TRIM_BLOCK)
+k_fq_trim_pack(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* __restrict__ start, const uint64_t* __restrict__ qstart,
+               const uint64_t* __restrict__ qend, uint64_t n, TrimDev T, uint64_t* __restrict__ k16, uint64_t* __restrict__ k48,
+               unsigned long long* counters) {
+    __shared__ uint32_t s_col[(TRIM_MAX_ALEN + 1) * TRIM_BLOCK];
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = start[i], qs = qstart[i], qe = qend[i];
+    if (s == FQ_NONE) s = size;
+    if (qs == FQ_NONE) qs = size;
+    if (qe == FQ_NONE) qe = size;
+    uint64_t ks[4], kn[2]; int len = 0;
+    int rc = trim_record(data, size, s, qs, qe, T, s_col + threadIdx.x, TRIM_BLOCK, ks, kn, len);
+    if (rc > 1) {
+        if (atomicCAS(&counters[2], 0ull, (unsigned long long)rc) == 0ull) counters[3] = i;
+        return;
+    }
+    if (rc == 0) return;
+    atomicAdd(&counters[4], 1ull);
+    if (!(kn[0] | kn[1]) && len <= 56) {
+        unsigned long long p = atomicAdd(&counters[0], 1ull);
+        k16[2 * p] = ks[0];
+        k16[2 * p + 1] = ks[1] | ((uint64_t)len << 56);
+    } else {
+        unsigned long long p = atomicAdd(&counters[1], 1ull);
+        k48[6 * p + 0] = ks[0]; k48[6 * p + 1] = ks[1]; k48[6 * p + 2] = ks[2];
+        k48[6 * p + 3] = ks[3] | ((uint64_t)len << 56);
+        k48[6 * p + 4] = kn[0]; k48[6 * p + 5] = kn[1];
+    }
+}
+
+// phred detection (trim_file.py:123-131): flags[0] = record 0 holds a quality character > 'J', flags[1] = any of
+// the first min(n, 1000) records does
+__global__ void __launch_bounds__(256)
+k_fq_phred(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* __restrict__ qstart, const uint64_t* __restrict__ qend,
+           uint64_t n, unsigned long long* flags) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || i >= 1000) return;
+    uint64_t qs = qstart[i], qe = qend[i];
+    if (qs == FQ_NONE) qs = size;
+    if (qe == FQ_NONE) qe = size;
+    bool hi = false;
+    for (uint64_t p = qs; p < qe; ++p) hi |= data[p] > 74;
+    if (hi) { atomicOr(&flags[1], 1ull); if (i == 0) atomicOr(&flags[0], 1ull); }
+}
+#endif
+
+}  // namespace mg

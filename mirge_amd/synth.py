@@ -321,3 +321,43 @@ def write_species_dir(path, libs, merges, with_dummy_ebwt=True):
     with open(os.path.join(path, "merges.csv"), "w") as f:
         for row in merges:
             f.write(",".join(row) + "\n")
+
+
+ILLUMINA_ADAPTER = "TGGAATTCTCGGGTGCCAAGGAACTCCAG"      # reference miRge.pl:82
+
+
+def make_raw_fastq(seqs, lens, seed: int, adapter: str = ILLUMINA_ADAPTER, read_len: int = 50, phred: int = 33,
+                   adapter_error: float = 0.15, low_tail: float = 0.25, crlf: bool = False) -> bytes:
+    """Raw reads as a sequencer writes them: insert + 3' adapter + random fill, cut to read_len.  A share
+    of the reads carries one or two errors (substitution / insertion / deletion) in the adapter part, a share a
+    low-quality 3' tail, a few a low-quality base in the middle or an N.  Returns FASTQ text."""
+    rng = np.random.default_rng(seed)
+    acgt = "ACGT"
+    hi, lo = chr(phred + 40), chr(phred + 2)
+    nl = "\r\n" if crlf else "\n"
+    out = []
+    for i in range(len(lens)):
+        ins = seqs[i, :lens[i]].tobytes().decode()
+        ad = list(adapter)
+        if rng.random() < adapter_error:
+            for _ in range(int(rng.integers(1, 3))):
+                p = int(rng.integers(0, len(ad))); kind = rng.random()
+                if kind < 0.6:
+                    ad[p] = acgt[(acgt.index(ad[p]) + int(rng.integers(1, 4))) % 4]
+                elif kind < 0.8:
+                    ad.insert(p, acgt[int(rng.integers(0, 4))])
+                else:
+                    del ad[p]
+        r = ins + "".join(ad) + "".join(acgt[int(x)] for x in rng.integers(0, 4, size=read_len))
+        r = r[:read_len]
+        q = [hi] * len(r)
+        if rng.random() < low_tail:
+            t = int(rng.integers(1, 20))
+            for p in range(max(0, len(r) - t), len(r)):
+                q[p] = lo if rng.random() < 0.85 else hi
+        if rng.random() < 0.05:
+            q[int(rng.integers(0, len(r)))] = lo
+        if rng.random() < 0.02:
+            p = int(rng.integers(0, len(r))); r = r[:p] + "N" + r[p + 1:]
+        out.append("@raw%d%s%s%s+%s%s%s" % (i, nl, r, nl, nl, "".join(q), nl))
+    return "".join(out).encode()

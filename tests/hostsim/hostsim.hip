@@ -4,6 +4,7 @@
 // and the product library has no such entry point.
 #include "../../mirge_amd/csrc/kernels.h"
 #include "../../mirge_amd/csrc/fastq.h"
+#include "../../mirge_amd/csrc/trim.h"
 #include <algorithm>
 #include <vector>
 #include <cstring>
@@ -114,6 +115,50 @@ int64_t sim_fastq(const uint8_t* data, uint64_t size, uint64_t win, uint64_t* ke
         else { k[0] = sq[0]; k[1] = sq[1]; k[2] = sq[2]; k[3] = sq[3] | ((uint64_t)len << 56); k[4] = nm[0]; k[5] = nm[1]; kw[i] = 6; }
     }
     return (int64_t)n;
+}
+
+// Raw FASTQ text through the device code of trim.h, record by record (index pass as sim_fastq, then trim_record).
+// keys: 6 words per KEPT record, kw = 2 / 6; out[0] = records, out[1] = kept, out[2] = phred base used, out[3] = phred
+// reported.  Returns kept, or -4 / -5 / -6 (the kernel's error codes), -1 bad spec / cap.
+int64_t sim_trim_fastq(const uint8_t* data, uint64_t size, const char* adapter, int32_t trim5, int32_t trim3,
+                       uint64_t* keys, int32_t* kw, uint64_t cap, int64_t* out) {
+    TrimDev T; std::string msg;
+    if (trim_dev_from_spec(adapter, trim5, trim3, T, msg)) return -1;
+    uint64_t newlines = 0;
+    for (uint64_t off = 0; off < size; off += FQ_TB) { uint32_t w[16]; fq_load64(data, size, off, w); newlines += fq_count64(w, off, size); }
+    uint64_t lines = newlines + ((size > 0 && data[size - 1] != '\n') ? 1 : 0);
+    uint64_t n = (lines + 3) / 4;
+    std::vector<uint64_t> st(n ? n : 1, FQ_NONE), qs(n ? n : 1, FQ_NONE), qe(n ? n : 1, FQ_NONE);
+    uint64_t o = 0;
+    for (uint64_t off = 0; off < size; off += FQ_TB) {
+        uint32_t w[16]; fq_load64(data, size, off, w);
+        uint32_t c = fq_count64(w, off, size);
+        if (c) fq_index64(w, off, size, 0, o, st.data(), qs.data(), qe.data());
+        o += c;
+    }
+    bool hi0 = false, hi = false;
+    for (uint64_t i = 0; i < n && i < 1000; ++i) {
+        uint64_t a = qs[i] == FQ_NONE ? size : qs[i], b = qe[i] == FQ_NONE ? size : qe[i];
+        for (uint64_t p = a; p < b; ++p) if (data[p] > 74) { hi = true; if (i == 0) hi0 = true; }
+    }
+    T.base = hi0 ? 64 : 33;
+    out[0] = (int64_t)n; out[2] = T.base; out[3] = hi ? 64 : 33;
+    uint64_t kept = 0;
+    uint32_t col[TRIM_MAX_ALEN + 1];
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t ks[4], kn[2]; int len = 0;
+        int rc = trim_record(data, size, st[i] == FQ_NONE ? size : st[i], qs[i] == FQ_NONE ? size : qs[i], qe[i] == FQ_NONE ? size : qe[i],
+                             T, col, 1, ks, kn, len);
+        if (rc > 1) return -rc;
+        if (rc == 0) continue;
+        if (kept >= cap) return -1;
+        uint64_t* k = keys + 6 * kept;
+        if (!(kn[0] | kn[1]) && len <= 56) { k[0] = ks[0]; k[1] = ks[1] | ((uint64_t)len << 56); kw[kept] = 2; }
+        else { k[0] = ks[0]; k[1] = ks[1]; k[2] = ks[2]; k[3] = ks[3] | ((uint64_t)len << 56); k[4] = kn[0]; k[5] = kn[1]; kw[kept] = 6; }
+        ++kept;
+    }
+    out[1] = (int64_t)kept;
+    return (int64_t)kept;
 }
 
 // newlines among the first `size` bytes, counted as k_fq_count does

@@ -1,0 +1,69 @@
+"""Trimming on the GPU (mirge_collapse_raw_fastq*) against the CPU restatement of trim_file.py + cutadapt
+(oracle/trim_oracle.c).  PARITY UNPINNED with respect to cutadapt itself: see tests/test_trim_cpu.py."""
+import collections
+
+import numpy as np
+import pytest
+
+from mirge_amd import capi, synth
+from oracle import trim as otrim
+from tests.test_trim_cpu import A, raw_case
+from tests.util import gpu_result_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(None, 1, 0)
+    yield c
+    c.close()
+
+
+def table(ctx):
+    return {k: v[3][0] for k, v in gpu_result_dict(ctx).items()}
+
+
+@pytest.mark.parametrize("seed,adapter,t5,t3,kw", [
+    (1, A, 0, 0, {}), (2, A, 1, 2, {}), (3, "illumina", 0, 0, {"read_len": 75}), (4, "none", 0, 0, {}), (5, "ion", 0, 0, {}),
+    (6, "+11", 2, 0, {}), (7, "-5", 0, 0, {}), (8, A, 0, 0, {"phred": 64}), (9, A, 0, 0, {"crlf": True}),
+    (10, "TGGAATTCTCGG," + A, 0, 0, {}), (11, A, 0, 0, {"adapter_error": 0.9, "low_tail": 0.6}), (12, A[:12], 3, 3, {"read_len": 36}),
+    (13, A, 0, 0, {"read_len": 124}),
+])
+def test_gpu_equals_restatement(ctx, tmp_path, seed, adapter, t5, t3, kw):
+    data = raw_case(seed, n=20000, **kw)
+    want, total, base, reported = otrim.trim_fastq(data, {"illumina": A, "ion": "+11"}.get(adapter, adapter), t5, t3)
+    expect = dict(collections.Counter(x.decode() for x in want))
+    ctx.reset()
+    assert ctx.collapse_raw_fastq_mem(data, 0, adapter, t5, t3) == (total, len(want), reported)
+    assert table(ctx) == expect
+    p = tmp_path / "raw.fastq"
+    p.write_bytes(data)
+    ctx.reset()
+    assert ctx.collapse_raw_fastq(str(p), 0, adapter, t5, t3) == (total, len(want), reported)
+    assert table(ctx) == expect
+
+
+def test_raw_equals_trimmed_path(ctx):
+    """Raw reads through the trimming step give the table the trimmed reads give through mirge_collapse_fastq_mem."""
+    data = raw_case(21, n=30000)
+    want, total, _, _ = otrim.trim_fastq(data, A)
+    trimmed = b"".join(b"@t\n" + s + b"\n+\n" + b"I" * len(s) + b"\n" for s in want)
+    ctx.reset(); ctx.collapse_fastq_mem(trimmed, 0); a = table(ctx)
+    ctx.reset(); ctx.collapse_raw_fastq_mem(data, 0, "illumina"); b = table(ctx)
+    assert a == b and len(a) > 100
+
+
+def test_errors(ctx):
+    for data, code in [(b"@r\nACGTACGTACGTACGTACGT\n+\nIIII\n", capi.MIRGE_E_FORMAT),
+                       (b"@r\n" + b"A" * 125 + b"\n+\n" + b"I" * 125 + b"\n", capi.MIRGE_E_LIMIT),
+                       (b"@r\nACGTACGTACGTACGTAXGT\n+\n" + b"I" * 20 + b"\n", capi.MIRGE_E_FORMAT)]:
+        ctx.reset()
+        with pytest.raises(capi.MirgeError) as e:
+            ctx.collapse_raw_fastq_mem(data, 0, "none")
+        assert e.value.code == code
+    for bad in ("ACGU", "A" * 33, "A,C,G,T,AA"):
+        with pytest.raises(capi.MirgeError):
+            ctx.collapse_raw_fastq_mem(b"", 0, bad)
+    ctx.reset()
+    assert ctx.collapse_raw_fastq_mem(b"", 0, "illumina") == (0, 0, 33)

@@ -1,0 +1,83 @@
+"""Trimming step (mirge_amd/csrc/trim.h, HOST build) against the CPU restatement of trim_file.py + cutadapt
+(oracle/trim_oracle.c).  PARITY UNPINNED with respect to cutadapt itself (not installed, no vector in the reference):
+these tests pin the device code to the restatement.  GPU run of the same cases: tests/test_gpu_trim.py."""
+import numpy as np
+import pytest
+
+from mirge_amd import synth
+from oracle import trim as otrim
+from tests.test_fastq_cpu import decode
+
+A = synth.ILLUMINA_ADAPTER
+
+
+def sim_trim(hostsim, data: bytes, adapter: str, trim5=0, trim3=0):
+    size = len(data)
+    pad = np.full((size + 15) // 16 * 16 + 16, ord("\n"), dtype=np.uint8)
+    pad[:size] = np.frombuffer(data, dtype=np.uint8)
+    cap = data.count(b"\n") // 4 + 2
+    keys = np.zeros((cap, 6), dtype=np.uint64); kw = np.zeros(cap, dtype=np.int32); out = np.zeros(4, dtype=np.int64)
+    n = hostsim.sim_trim_fastq(pad.ctypes.data, size, adapter.encode(), trim5, trim3, keys.ctypes.data, kw.ctypes.data, cap, out.ctypes.data)
+    if n < 0:
+        return n
+    return [decode(keys[i], int(kw[i])) for i in range(n)], int(out[0]), int(out[2]), int(out[3])
+
+
+def raw_case(seed, n=1500, **kw):
+    libs, _ = synth.make_libraries(synth.Profile.tiny(), 900 + seed)
+    seqs, lens = synth.make_reads(libs, n, 910 + seed)
+    return synth.make_raw_fastq(seqs, lens, 920 + seed, **kw)
+
+
+def test_known_answers():
+    ins = b"TGAGGTAGTAGGTTGTATAGTT"
+    ab = A.encode()
+    assert otrim.adapter_back(ab, ins + ab[:28])[2] == 22                     # the read ends inside the adapter
+    assert otrim.adapter_back(ab, ins + ab + b"ACGT")[2:4] == (22, 51)         # whole adapter, leftmost exact occurrence
+    assert otrim.adapter_back(ab, ins + b"TGG")[2] == 22                       # 3-nt overlap is the minimum ...
+    assert otrim.adapter_back(ab, ins + b"TG") is None                         # ... 2 nt are not removed
+    r = bytearray(ins + ab[:28]); r[30] = ord("C") if r[30] != ord("C") else ord("A")
+    assert otrim.adapter_back(ab, bytes(r)) == (0, 28, 22, 50, 27, 1)          # one substitution: 1 <= int(28 * 0.12) = 3
+    r = bytearray(ins + ab[:8]); r[25] = ord("C") if r[25] != ord("C") else ord("A")
+    m = otrim.adapter_back(ab, bytes(r))
+    assert m is None or m[5] == 0                                               # 8 nt allow no error: int(8 * 0.12) = 0
+    assert otrim.quality_trim(b"IIIIIIIIII####") == (0, 10)
+    assert otrim.quality_trim(b"IIII#III##") == (0, 8)                          # BWA: the best cut, not the first low base
+    assert otrim.quality_trim(b"####") == (0, 0)
+
+
+@pytest.mark.parametrize("seed,adapter,t5,t3,kw", [
+    (1, A, 0, 0, {}), (2, A, 1, 2, {}), (3, "illumina", 0, 0, {"read_len": 75}), (4, "none", 0, 0, {}), (5, "ion", 0, 0, {}),
+    (6, "+11", 2, 0, {}), (7, "-5", 0, 0, {}), (8, A, 0, 0, {"phred": 64}), (9, A, 0, 0, {"crlf": True}),
+    (10, "TGGAATTCTCGG," + A, 0, 0, {}), (11, A, 0, 0, {"adapter_error": 0.9, "low_tail": 0.6}), (12, A[:12], 3, 3, {"read_len": 36}),
+    (13, A, 0, 0, {"read_len": 124}),
+])
+def test_host_build_equals_restatement(hostsim, seed, adapter, t5, t3, kw):
+    data = raw_case(seed, **kw)
+    want, total, base, reported = otrim.trim_fastq(data, {"illumina": A, "ion": "+11"}.get(adapter, adapter), t5, t3)
+    got = sim_trim(hostsim, data, adapter, t5, t3)
+    assert not isinstance(got, int), got
+    assert got[1] == total and got[2] == base and got[3] == reported
+    assert got[0] == want
+    assert 0 < len(want) <= total
+    if adapter not in ("none",) and not adapter.startswith(("+", "-")) and adapter != "ion":
+        assert len(set(len(x) for x in want)) > 5          # the adapters were found: lengths spread like the inserts
+
+
+def test_phred_is_decided_on_the_first_record(hostsim):
+    # record 0 all below 'K', a later record above: the workers keep base 33, miRge.pl is told 64 (trim_file.py:123-131)
+    rec = lambda q: b"@r\n" + b"ACGTACGTACGTACGTACGT" + b"\n+\n" + q * 20 + b"\n"
+    data = rec(b"I") + rec(b"h") + rec(b"I")
+    got = sim_trim(hostsim, data, "none")
+    assert got[2] == 33 and got[3] == 64
+    assert (got[2], got[3]) == otrim.trim_fastq(data, "none")[2:]
+    data = rec(b"h") + rec(b"I")
+    got = sim_trim(hostsim, data, "none")
+    assert got[2] == 64 and got[3] == 64 and got[0] == otrim.trim_fastq(data, "none")[0]
+
+
+def test_errors(hostsim):
+    assert sim_trim(hostsim, b"@r\nACGTACGTACGTACGTACGT\n+\nIIII\n", "none") == -6        # quality line shorter than the sequence
+    assert sim_trim(hostsim, b"@r\n" + b"A" * 125 + b"\n+\n" + b"I" * 125 + b"\n", "none") == -5
+    assert sim_trim(hostsim, b"@r\nACGTACGTACGTACGTAXGT\n+\n" + b"I" * 20 + b"\n", "none") == -4
+    assert sim_trim(hostsim, b"", "none")[0] == []
