@@ -30,7 +30,10 @@ def perl_num(x) -> str:
 class MirgeRun:
     """State of one miRge run: $seqHash / $mirHash / $logHash of miRge.pl:99-104, device-backed."""
 
-    def __init__(self, species_dir, sample_files, sample_names=None, device=0, ctx=None):
+    def __init__(self, species_dir, sample_files, sample_names=None, device=0, ctx=None, adapter=None, trim5=0, trim3=0):
+        # adapter (miRge.pl:80-86 `--adapter`): None = the sample files are already trimmed (the hot path proper);
+        # "none" / "illumina" / "ion" / "+N" / a sequence = they are raw and go through the device trimming step
+        self.adapter, self.trim5, self.trim3 = adapter, int(trim5), int(trim3)
         self.sampleFiles = list(sample_files)
         self.sampleNames = list(sample_names) if sample_names else list(sample_files)   # miRge.pl:73-78
         self.S = len(self.sampleFiles)
@@ -46,6 +49,14 @@ class MirgeRun:
         n = self.ctx.collapse_fastq(infile, sampleIndex)
         self.logHash["quantStats"][sampleIndex]["trimmedReads"] = n
         return n
+
+    # ---- miRge.pl:259-262: trimRaw (python trim_file.py) + `cutadapt -u` + quantReads in one device pass
+    def trimAndQuantReads(self, infile, sampleIndex):
+        total, kept, phred = self.ctx.collapse_raw_fastq(infile, sampleIndex, self.adapter, self.trim5, self.trim3)
+        q = self.logHash["quantStats"][sampleIndex]
+        q["totalReads"], q["trimmedReads"] = total, kept       # miRge.pl:285-288
+        self.phred64 = phred == 64                             # miRge.pl:278
+        return kept
 
     def quantReadsFromList(self, reads, sampleIndex, lens=None):
         self.ctx.collapse_seqs(reads, sampleIndex, lens)
@@ -181,7 +192,10 @@ class MirgeRun:
         """quantReads per sample -> runAnnotationPipeline -> summarize -> miRNAmerge -> filter ->
         writeDataToCSV: miRge.pl:133-150 without trimming, graphs and HTML."""
         for i, f in enumerate(self.sampleFiles):
-            self.quantReads(f, i)
+            if self.adapter is None:
+                self.quantReads(f, i)
+            else:
+                self.trimAndQuantReads(f, i)
         self.runAnnotationPipeline()
         self.summarize()
         self.miRNAmerge()

@@ -361,3 +361,33 @@ def make_raw_fastq(seqs, lens, seed: int, adapter: str = ILLUMINA_ADAPTER, read_
             p = int(rng.integers(0, len(r))); r = r[:p] + "N" + r[p + 1:]
         out.append("@raw%d%s%s%s+%s%s%s" % (i, nl, r, nl, nl, "".join(q), nl))
     return "".join(out).encode()
+
+
+def write_raw_fastq_fast(path, seqs, lens, seed: int, adapter: str = ILLUMINA_ADAPTER, read_len: int = 50, block=1 << 20):
+    """Raw fixed-length reads (insert + adapter + random fill, cut to read_len; a quarter with a low-quality 3' tail),
+    assembled with numpy for bench.py's multi-million-read raw leg.  Returns the number of bytes written."""
+    rng = np.random.default_rng(seed)
+    n, W = seqs.shape
+    u8 = np.uint8
+    ad = np.frombuffer(adapter.encode(), dtype=u8)
+    acgt = np.frombuffer(b"ACGT", dtype=u8)
+    total = 0
+    with open(path, "wb") as f:
+        for b in range(0, n, block):
+            sq = seqs[b:b + block]; l = lens[b:b + block].astype(np.int64); m = len(l)
+            j = np.arange(read_len, dtype=np.int64)[None, :]
+            rel = j - l[:, None]
+            row = acgt[rng.integers(0, 4, size=(m, read_len))]
+            ins = rel < 0
+            row[ins] = np.take_along_axis(np.pad(sq, ((0, 0), (0, max(0, read_len - W)))), np.broadcast_to(j, (m, read_len)), axis=1)[ins]
+            ina = (rel >= 0) & (rel < len(ad))
+            row[ina] = ad[np.clip(rel, 0, len(ad) - 1)][ina]
+            qual = np.full((m, read_len), ord("I"), u8)
+            tail = rng.integers(1, 20, size=m) * (rng.random(m) < 0.25)
+            qual[j >= (read_len - tail)[:, None]] = ord("#")
+            idx = np.arange(b, b + m, dtype=np.int64)
+            digits = ((idx[:, None] // 10 ** np.arange(8, -1, -1, dtype=np.int64)[None, :]) % 10 + 48).astype(u8)
+            rec = np.concatenate([np.full((m, 1), ord("@"), u8), np.full((m, 1), ord("r"), u8), digits, np.full((m, 1), 10, u8),
+                                  row, np.tile(np.frombuffer(b"\n+\n", dtype=u8), (m, 1)), qual, np.full((m, 1), 10, u8)], axis=1)
+            f.write(rec.tobytes()); total += rec.size
+    return total

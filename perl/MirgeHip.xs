@@ -64,6 +64,24 @@ mirge_collapse_fastq(ctx, path, sample)
         RETVAL
 
 void
+mirge_collapse_raw_fastq(ctx, path, sample, adapter, trim5, trim3)
+        MirgeHip ctx
+        const char* path
+        int sample
+        const char* adapter
+        int trim5
+        int trim3
+    PREINIT:
+        uint64_t total = 0, kept = 0; int32_t phred = 33;
+    PPCODE:
+        if (mirge_collapse_raw_fastq(ctx, path, sample, adapter, trim5, trim3, &total, &kept, &phred) != MIRGE_OK)
+            croak("MirgeHip::collapse_raw_fastq: %s", mirge_last_error(ctx));
+        EXTEND(SP, 3);
+        PUSHs(sv_2mortal(newSVuv((UV)total)));
+        PUSHs(sv_2mortal(newSVuv((UV)kept)));
+        PUSHs(sv_2mortal(newSViv((IV)phred)));
+
+void
 mirge_annotate(ctx)
         MirgeHip ctx
     CODE:
