@@ -31,6 +31,8 @@ struct LibDev {
     const uint64_t* kpre;        // kent order: the middle 32 nt of each entry's context, text[pos-12, pos+20) -- 8-byte pre-filter for long scans
     const uint32_t* kbits;       // 1 bit per bucket: non-empty?  (4^kb / 8 bytes: cache-resident where koff is not)
     const uint32_t* ref_start;   // n_refs + 1 text coordinates
+    const uint32_t* ref_lut;     // ref_lut[s] = reference that holds text position s << lut_shift (T >> lut_shift) + 2 entries
+    int32_t  lut_shift;
     uint32_t n_refs;
     uint32_t T;                  // text length in nt, separators included
     int32_t  kb;
@@ -468,10 +470,27 @@ MG_HD uint64_t spread32(uint32_t v) {
     return x;
 }
 
+// largest j with ref_start[j] <= pos.  A binary search over all references is ~15 DEPENDENT loads for a 20k-40k
+// entry library, three times per aligned read: the segment table narrows it to the references that begin inside
+// one 2^lut_shift-nt segment (one 8-byte load, then 0-2 steps).
 MG_HD uint32_t ref_of(const LibDev& L, uint32_t pos) {
-    uint32_t lo = 0, hi = L.n_refs;            // largest j with ref_start[j] <= pos
+    const uint32_t sgm = pos >> L.lut_shift;
+    uint32_t lo = L.ref_lut[sgm], hi = L.ref_lut[sgm + 1] + 1;
+    if (hi > L.n_refs) hi = L.n_refs;
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (L.ref_start[mid] <= pos) lo = mid; else hi = mid; }
     return lo;
+}
+// host: the segment table of ref_of (n + 1 starts, text length T)
+inline int ref_lut_shift(uint64_t T) { int sh = 5; while ((T >> sh) > (1u << 20)) ++sh; return sh; }
+template <class Vec> inline void build_ref_lut(const uint32_t* ref_start, uint32_t n, uint64_t T, int shift, Vec& lut) {
+    const uint64_t nseg = (T >> shift) + 2;
+    lut.assign((size_t)nseg, 0);
+    uint32_t j = 0;
+    for (uint64_t sg = 0; sg < nseg; ++sg) {
+        const uint64_t pos = sg << shift;
+        while (j + 1 < n && ref_start[j + 1] <= pos) ++j;
+        lut[(size_t)sg] = j;
+    }
 }
 
 // Pigeonhole pieces.  An alignment has <= seedmm mismatches in the seed and <= maxmm overall, so one
@@ -890,8 +909,14 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         if (score) {
             hit = true;
             ann_round[u] = (uint8_t)(RN + 1);
-            ann_ref[u] = (int32_t)ref_of(L, (uint32_t)(score >> 1));
-            ann_amb[u] = (uint8_t)(ref_of(L, (uint32_t)s_best[MB + tid]) != ref_of(L, 0xFFFFFFFFu - (uint32_t)s_best[2 * MB + tid]));
+            const uint32_t r = ref_of(L, (uint32_t)(score >> 1));
+            ann_ref[u] = (int32_t)r;
+            // ambiguous = the best stratum spans more than one reference; its extremes usually lie in r itself
+            const uint32_t pmax = (uint32_t)s_best[MB + tid], pmin = 0xFFFFFFFFu - (uint32_t)s_best[2 * MB + tid];
+            const uint32_t r0 = L.ref_start[r], r1 = L.ref_start[r + 1];
+            bool amb = false;
+            if (pmin < r0 || pmax >= r1) amb = ref_of(L, pmax) != ref_of(L, pmin);
+            ann_amb[u] = (uint8_t)amb;
         }
     }
     // counters are spread over STAT_SLOTS cache lines: one hot word would cost ~12 ns per wave

@@ -60,15 +60,16 @@ struct Lib {
     std::vector<uint32_t> ref_start;     // n + 1
     uint64_t T = 0;
     int kb = 0;
-    DevBuf text, bad, koff, kent, kpre, kbits, dref;
+    DevBuf text, bad, koff, kent, kpre, kbits, dref, dlut; int lut_shift = 5;
     LibDev dev() const {
         LibDev L;
         L.text = text.as<uint64_t>(); L.bad = bad.as<uint64_t>(); L.koff = koff.as<uint32_t>();
         L.kent = kent.as<KEnt>(); L.kpre = kpre.as<uint64_t>(); L.kbits = kbits.as<uint32_t>(); L.ref_start = dref.as<uint32_t>();
+        L.ref_lut = dlut.as<uint32_t>(); L.lut_shift = lut_shift;
         L.n_refs = (uint32_t)names.size(); L.T = (uint32_t)T; L.kb = kb;
         return L;
     }
-    void release() { text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); loaded = false; }
+    void release() { text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); loaded = false; }
 };
 
 constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
@@ -216,6 +217,11 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     HIPCHK(c, hipMemcpyAsync(L.text.p, text.data(), words * 8, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(L.bad.p, bad.data(), bwords * 8, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(L.dref.p, L.ref_start.data(), (n + 1) * 4, hipMemcpyHostToDevice, c->st));
+    std::vector<uint32_t> lut;
+    L.lut_shift = ref_lut_shift(T);
+    build_ref_lut(L.ref_start.data(), (uint32_t)n, T, L.lut_shift, lut);
+    HIPCHK(c, L.dlut.ensure(lut.size() * 4, false, 0, c->st));
+    HIPCHK(c, hipMemcpyAsync(L.dlut.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (nb + 1) * 4, c->st));
     if (T > 0) {
         uint32_t grid = (uint32_t)((T + 255) / 256);

@@ -12,10 +12,10 @@ using namespace mg;
 
 struct SimLib {
     std::vector<uint64_t> text, bad;
-    std::vector<uint32_t> koff, ref_start, kbits; std::vector<KEnt> kent; std::vector<uint64_t> kpre;
+    std::vector<uint32_t> koff, ref_start, kbits, lut; int lut_shift = 5; std::vector<KEnt> kent; std::vector<uint64_t> kpre;
     uint32_t T; int kb;
     LibDev dev() const { LibDev L; L.text = text.data(); L.bad = bad.data(); L.koff = koff.data(); L.kent = kent.data(); L.kpre = kpre.data(); L.kbits = kbits.data();
-                         L.ref_start = ref_start.data(); L.n_refs = (uint32_t)ref_start.size() - 1; L.T = T; L.kb = kb; return L; }
+                         L.ref_start = ref_start.data(); L.ref_lut = lut.data(); L.lut_shift = lut_shift; L.n_refs = (uint32_t)ref_start.size() - 1; L.T = T; L.kb = kb; return L; }
 };
 
 extern "C" {
@@ -38,6 +38,8 @@ void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb)
         S->bad[p >> 6] |= 1ull << (p & 63); ++p;
     }
     S->ref_start[n] = (uint32_t)p; S->T = (uint32_t)T; S->kb = kb;
+    S->lut_shift = ref_lut_shift(T);
+    build_ref_lut(S->ref_start.data(), (uint32_t)n, T, S->lut_shift, S->lut);
     uint64_t nb = 1ull << (2 * kb);
     S->koff.assign(nb + 1, 0); S->kent.assign(T ? T : 1, KEnt{0, 0, 0, 0});
     for (uint32_t q = 0; q < T; ++q) S->koff[text_kmer(S->text.data(), q, kb) + 1]++;
