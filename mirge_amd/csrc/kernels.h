@@ -658,7 +658,9 @@ MG_HD bool pre_pass(const PreAl& R, uint64_t pv, int maxmm) {
 MG_HD void koff_range(const LibDev& L, uint64_t b0, uint64_t b1, uint32_t& lo, uint32_t& hi) {
     lo = 0; hi = 0;
     if (b1 == b0 + 1) {
-        if (!((L.kbits[b0 >> 5] >> (b0 & 31)) & 1)) return;          // empty bucket
+        // the occupancy bit first -- unless koff itself is small enough to stay cache-resident (kbits == null): then
+        // asking it would only put one more load in front of the dependent chain bitmap -> offsets -> entry
+        if (L.kbits && !((L.kbits[b0 >> 5] >> (b0 & 31)) & 1)) return;          // empty bucket
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
         u32x2 v = *reinterpret_cast<const u32x2*>(L.koff + b0);
         lo = v.x; hi = v.y;
@@ -784,13 +786,19 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     s_u[tid] = u;
     bool active = false;
     uint64_t k[KW];
-    if (u != EMPTY && (list || ann_round[u] == 0)) {
+    // key and annotation state are fetched side by side (the key of an already annotated unique is a wasted load,
+    // a load that waits for the state is a longer dependent chain for everyone else)
+    uint8_t done_before = 0;
+    if (u != EMPTY) {
+        if (!list) done_before = ann_round[u];
 #pragma unroll
         for (int w = 0; w < KW; ++w) k[w] = ukeys[(uint64_t)u * KW + w];
+    }
+    const bool listed = u != EMPTY && done_before == 0;
+    if (listed) {
         int len = key_len<KW>(k);
         active = !(P.len_lt && !(len < P.len_lt)) && !(P.len_gt && !(len > P.len_gt));
     }
-    const bool listed = u != EMPTY && (list || ann_round[u] == 0);
     if (!__syncthreads_or(active) && !next_list) return;
     s_best[tid] = 0; s_best[MB + tid] = 0; s_best[2 * MB + tid] = 0;
     if (tid == 0) { s_qn = 0; s_next = 0; }

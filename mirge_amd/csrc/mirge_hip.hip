@@ -61,10 +61,11 @@ struct Lib {
     uint64_t T = 0;
     int kb = 0;
     DevBuf text, bad, koff, kent, kpre, kbits, dref, dlut; int lut_shift = 5;
+    bool use_bits = true;                // false: koff is small enough to stay in L2, the occupancy bitmap is skipped
     LibDev dev() const {
         LibDev L;
         L.text = text.as<uint64_t>(); L.bad = bad.as<uint64_t>(); L.koff = koff.as<uint32_t>();
-        L.kent = kent.as<KEnt>(); L.kpre = kpre.as<uint64_t>(); L.kbits = kbits.as<uint32_t>(); L.ref_start = dref.as<uint32_t>();
+        L.kent = kent.as<KEnt>(); L.kpre = kpre.as<uint64_t>(); L.kbits = use_bits ? kbits.as<uint32_t>() : nullptr; L.ref_start = dref.as<uint32_t>();
         L.ref_lut = dlut.as<uint32_t>(); L.lut_shift = lut_shift;
         L.n_refs = (uint32_t)names.size(); L.T = (uint32_t)T; L.kb = kb;
         return L;
@@ -202,9 +203,15 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     for (auto& nm : L.names) { size_t e = nm.find_first_of(" \t"); L.short_names.push_back(e == std::string::npos ? nm : nm.substr(0, e)); }
     int kb = (int)std::lround(std::log2((double)std::max<uint64_t>(T, 16)) / 2.0) + 1;   // ~0.25 random entries per bucket
     L.kb = std::min(14, std::max(4, kb));
+    L.use_bits = true;
     if (const char* env = getenv("MIRGE_KB_BIAS")) L.kb = std::min(14, std::max(4, L.kb + atoi(env)));   // tuning aid
     if (const char* env = getenv("MIRGE_KB")) { if (atoi(env) >= 2 && atoi(env) <= 15) L.kb = atoi(env); }   // tests
     uint64_t nb = 1ull << (2 * L.kb);
+    {
+        uint64_t lim = 8ull << 20;                                    // koff bytes that stay cache-resident (MIRGE_BITS_ABOVE)
+        if (const char* env = getenv("MIRGE_BITS_ABOVE")) lim = strtoull(env, nullptr, 10);
+        L.use_bits = nb * 4 > lim;
+    }
     HIPCHK(c, L.text.ensure(words * 8, false, 0, c->st));
     HIPCHK(c, L.bad.ensure(bwords * 8, false, 0, c->st));
     HIPCHK(c, L.dref.ensure((n + 1) * 4, false, 0, c->st));
