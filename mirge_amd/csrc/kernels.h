@@ -790,7 +790,10 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     // a load that waits for the state is a longer dependent chain for everyone else)
     uint8_t done_before = 0;
     if (u != EMPTY) {
-        if (!list) done_before = ann_round[u];
+        // the first round of a cascade (always a walk over the whole table) leaves the "not annotated" state behind
+        // instead of reading it: the host fills none of the three arrays
+        if (RN == 0) { ann_round[u] = 0; ann_ref[u] = -1; ann_amb[u] = 0; }
+        else if (!list) done_before = ann_round[u];
 #pragma unroll
         for (int w = 0; w < KW; ++w) k[w] = ukeys[(uint64_t)u * KW + w];
     }

@@ -85,10 +85,18 @@ struct Class {
     DevBuf ukeys, coo_g, coo_c;
     DevBuf gslots; uint64_t gcap = 0; bool gvalid = false;     // cross-sample table, built lazily
     DevBuf ann_round, ann_ref, ann_amb;
-    DevBuf act[2], act_n;                       // ping-pong lists of still-unannotated uniques + their lengths
+    DevBuf act[2];                              // ping-pong lists of still-unannotated uniques
+    unsigned long long* act_n = nullptr;        // their lengths (device; lives in the context's state arena)
+    // The two classes run side by side (the 48-byte class is tiny: its kernels are latency-, not throughput-bound):
+    // each has its own stream and its own collapse workspaces.
+    hipStream_t st = nullptr;
+    DevBuf ws_lslots, ws_cnt, ws_cnt0, ws_ctr;
+    unsigned long long* h_ctr = nullptr;        // pinned, 4 words
+    uint32_t pend_n = 0; int pend_sample = 0; bool pending = false;     // a collapse launched, not yet finished
     std::vector<Segment> segs;
     void reset() { U = 0; coo_n = 0; gvalid = false; segs.clear(); }
-    void release() { ukeys.release(); coo_g.release(); coo_c.release(); gslots.release(); act[0].release(); act[1].release(); act_n.release(); ann_round.release(); ann_ref.release(); ann_amb.release(); }
+    void release() { ukeys.release(); coo_g.release(); coo_c.release(); gslots.release(); act[0].release(); act[1].release(); ann_round.release(); ann_ref.release(); ann_amb.release();
+                     ws_lslots.release(); ws_cnt.release(); ws_cnt0.release(); ws_ctr.release(); }
 };
 
 struct KTime { const char* name; hipEvent_t a = nullptr, b = nullptr; bool used = false; double ms = 0; uint64_t bytes = 0; };
@@ -98,7 +106,8 @@ struct KTime { const char* name; hipEvent_t a = nullptr, b = nullptr; bool used 
 struct mirge_ctx {
     int device = 0;
     int S = 1;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr, st2 = nullptr;        // st: everything; st2: the 48-byte key class inside collapse_packed / annotate
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     Lib libs[MIRGE_N_LIBS];
     int n_rounds = 5;
@@ -108,13 +117,16 @@ struct mirge_ctx {
     mirge_round rounds[MIRGE_MAX_ROUNDS];
     Class cls[2];                                   // [0] 16-byte keys, [1] 48-byte keys
     // workspaces
-    DevBuf lslots, cnt, cnt0, rep, ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist;
+    DevBuf rep, ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist;
     DevBuf sh_ctr, sh_w[2];                         // multi-GPU exchange: per-owner / per-sample counters, weights of imported records
     int sh_world = 0; uint64_t sh_n[2][SHARD_MAX_WORLD] = {};
     DevBuf fq_raw, fq_seg, fq_segb, fq_start, fq_qstart, fq_qend;       // FASTQ ingest: raw file bytes, newline counts per segment (+ scanned), record starts
     uint8_t* fq_pin = nullptr;                      // pinned staging ring for file -> HBM streaming (FQ_SLOTS x FQ_SLOT_BYTES)
     double ingest_ms = 0;                           // wall time of the last file -> HBM transfer
-    DevBuf d_stats, d_quant, d_iscan, d_cat, d_len, d_tu;
+    // everything a run starts from zero and hands back lives in ONE arena: [round stats | quant | iscan | categories |
+    // length histogram | trimmedUniq | survivor-list lengths x 2] -- one memset before the cascade, one copy to the host after it
+    DevBuf state; unsigned long long* h_state = nullptr; size_t h_state_cap = 0;
+    unsigned long long *d_stats = nullptr, *d_quant = nullptr, *d_iscan = nullptr, *d_cat = nullptr, *d_len = nullptr, *d_tu = nullptr;
     unsigned long long* h_ctr = nullptr;            // pinned, 16 words
     // results
     bool annotated = false, counts_valid = false, host_valid = false;
@@ -150,8 +162,17 @@ KTime& ktime(mirge_ctx* c, const char* name) {
     c->kt.push_back(k);
     return c->kt.back();
 }
-void kt_begin(mirge_ctx* c, const char* name) { KTime& k = ktime(c, name); (void)hipEventRecord(k.a, c->st); }
-void kt_end(mirge_ctx* c, const char* name, uint64_t bytes) { KTime& k = ktime(c, name); (void)hipEventRecord(k.b, c->st); k.used = true; k.bytes = bytes; k.ms = -1; }
+void kt_begin(mirge_ctx* c, const char* name, hipStream_t st = nullptr) { KTime& k = ktime(c, name); (void)hipEventRecord(k.a, st ? st : c->st); }
+void kt_end(mirge_ctx* c, const char* name, uint64_t bytes, hipStream_t st = nullptr) { KTime& k = ktime(c, name); (void)hipEventRecord(k.b, st ? st : c->st); k.used = true; k.bytes = bytes; k.ms = -1; }
+// st2 picks up after everything queued on st so far / st waits for everything queued on st2 so far
+int fork_st2(mirge_ctx* c) {
+    if (hipEventRecord(c->ev_fork, c->st) != hipSuccess || hipStreamWaitEvent(c->st2, c->ev_fork, 0) != hipSuccess) return fail(c, MIRGE_E_HIP, "stream fork failed");
+    return MIRGE_OK;
+}
+int join_st2(mirge_ctx* c) {
+    if (hipEventRecord(c->ev_join, c->st2) != hipSuccess || hipStreamWaitEvent(c->st, c->ev_join, 0) != hipSuccess) return fail(c, MIRGE_E_HIP, "stream join failed");
+    return MIRGE_OK;
+}
 void kt_resolve(mirge_ctx* c) {
     for (auto& k : c->kt) if (k.used && k.ms < 0) { float ms = 0; if (hipEventElapsedTime(&ms, k.a, k.b) == hipSuccess) k.ms = ms; else k.ms = 0; }
 }
@@ -277,37 +298,41 @@ int load_fasta(mirge_ctx* c, int lib, const char* path) {
     return load_library(c, lib, std::move(names), seqs.data(), offs.data());
 }
 
-// ---- collapse of one key class
+// ---- collapse of one key class, in two halves so that the two classes overlap: everything up to the emit kernel is
+// queued on the class's stream by collapse_launch; collapse_finish waits for it, learns how many uniques were new
+// and appends the sample's segment.
 template <int KW>
-int collapse_class(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64, int sample, const char* tagA, const char* tagB,
-                   const uint32_t* d_wt = nullptr) {
+int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64, int sample, const char* tagA, const char* tagB,
+                    const uint32_t* d_wt = nullptr) {
     if (n64 >= 0xFFFFFFF0ull) return fail(c, MIRGE_E_LIMIT, "more than 2^32 reads in one collapse call");
     if (C.U + n64 >= 0xFFFFFFF0ull) return fail(c, MIRGE_E_LIMIT, "more than 2^32 unique sequences");
     uint32_t n = (uint32_t)n64;
-    if (n == 0) { C.segs.push_back({sample, C.coo_n, 0}); return MIRGE_OK; }
+    C.pending = true; C.pend_n = n; C.pend_sample = sample;
+    if (n == 0) return MIRGE_OK;
+    hipStream_t st = C.st;
     uint64_t capL = pow2_at_least((uint64_t)n + n / 4);      // load <= 0.8 even if every read is distinct; smaller table = more of it cache-resident
-    HIPCHK(c, c->lslots.ensure(capL * 4, false, 0, c->st));
-    HIPCHK(c, c->cnt.ensure((size_t)n * 4, false, 0, c->st));
-    HIPCHK(c, c->cnt0.ensure((size_t)n * 4, false, 0, c->st));
-    HIPCHK(c, c->ctr.ensure(64, false, 0, c->st));
-    HIPCHK(c, C.ukeys.ensure((C.U + n) * KW * 8, true, C.U * KW * 8, c->st));
-    HIPCHK(c, C.coo_g.ensure((C.coo_n + n) * 4, true, C.coo_n * 4, c->st));
-    HIPCHK(c, C.coo_c.ensure((C.coo_n + n) * 4, true, C.coo_n * 4, c->st));
+    HIPCHK(c, C.ws_lslots.ensure(capL * 4, false, 0, st));
+    HIPCHK(c, C.ws_cnt.ensure((size_t)n * 4, false, 0, st));
+    HIPCHK(c, C.ws_cnt0.ensure((size_t)n * 4, false, 0, st));
+    HIPCHK(c, C.ws_ctr.ensure(64, false, 0, st));
+    HIPCHK(c, C.ukeys.ensure((C.U + n) * KW * 8, true, C.U * KW * 8, st));
+    HIPCHK(c, C.coo_g.ensure((C.coo_n + n) * 4, true, C.coo_n * 4, st));
+    HIPCHK(c, C.coo_c.ensure((C.coo_n + n) * 4, true, C.coo_n * 4, st));
     bool use_g = C.U > 0;
     if (use_g) {
         uint64_t need = pow2_at_least(2ull * (C.U + n));
         if (!C.gvalid || C.gcap < need) {
-            HIPCHK(c, C.gslots.ensure(need * 4, false, 0, c->st));
+            HIPCHK(c, C.gslots.ensure(need * 4, false, 0, st));
             C.gcap = need;
-            HIPCHK(c, hipMemsetAsync(C.gslots.p, 0xFF, need * 4, c->st));
-            hipLaunchKernelGGL((k_gtable_insert<KW>), dim3((uint32_t)((C.U + 255) / 256)), dim3(256), 0, c->st,
+            HIPCHK(c, hipMemsetAsync(C.gslots.p, 0xFF, need * 4, st));
+            hipLaunchKernelGGL((k_gtable_insert<KW>), dim3((uint32_t)((C.U + 255) / 256)), dim3(256), 0, st,
                                C.ukeys.as<uint64_t>(), 0u, (uint32_t)C.U, C.gslots.as<uint32_t>(), (uint32_t)(C.gcap - 1));
             C.gvalid = true;
         }
     }
-    HIPCHK(c, hipMemsetAsync(c->lslots.p, 0xFF, capL * 4, c->st));
-    HIPCHK(c, hipMemsetAsync(c->cnt.p, 0, (size_t)n * 4, c->st));
-    HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 64, c->st));
+    HIPCHK(c, hipMemsetAsync(C.ws_lslots.p, 0xFF, capL * 4, st));
+    HIPCHK(c, hipMemsetAsync(C.ws_cnt.p, 0, (size_t)n * 4, st));
+    HIPCHK(c, hipMemsetAsync(C.ws_ctr.p, 0, 64, st));
 #ifndef MG_CL_T
 #define MG_CL_T 2048
 #endif
@@ -316,30 +341,54 @@ int collapse_class(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64,
 #endif
     constexpr int T = KW == 2 ? MG_CL_T : 512;
     constexpr int CB = KW == 2 ? MG_CL_B : 256;
-    kt_begin(c, tagA);
-    hipLaunchKernelGGL((k_collapse_local<KW, T, CB>), dim3((n + T - 1) / T), dim3(CB), 0, c->st,
-                       d_keys, d_wt, n, c->lslots.as<uint32_t>(), (uint32_t)(capL - 1), c->cnt.as<uint32_t>(), c->cnt0.as<uint32_t>(), (uint32_t*)nullptr);
-    kt_end(c, tagA, (uint64_t)n * KW * 8);
-    kt_begin(c, tagB);
-    hipLaunchKernelGGL((k_collapse_emit<KW>), dim3((n + 256 * EMIT_PER - 1) / (256 * EMIT_PER)), dim3(256), 0, c->st,
-                       d_keys, c->cnt.as<uint32_t>(), c->cnt0.as<uint32_t>(), n, use_g ? C.gslots.as<uint32_t>() : (const uint32_t*)nullptr,
+    kt_begin(c, tagA, st);
+    hipLaunchKernelGGL((k_collapse_local<KW, T, CB>), dim3((n + T - 1) / T), dim3(CB), 0, st,
+                       d_keys, d_wt, n, C.ws_lslots.as<uint32_t>(), (uint32_t)(capL - 1), C.ws_cnt.as<uint32_t>(), C.ws_cnt0.as<uint32_t>(), (uint32_t*)nullptr);
+    kt_end(c, tagA, (uint64_t)n * KW * 8, st);
+    kt_begin(c, tagB, st);
+    hipLaunchKernelGGL((k_collapse_emit<KW>), dim3((n + 256 * EMIT_PER - 1) / (256 * EMIT_PER)), dim3(256), 0, st,
+                       d_keys, C.ws_cnt.as<uint32_t>(), C.ws_cnt0.as<uint32_t>(), n, use_g ? C.gslots.as<uint32_t>() : (const uint32_t*)nullptr,
                        (uint32_t)(C.gcap ? C.gcap - 1 : 0), C.ukeys.as<uint64_t>(), (uint32_t)C.U,
                        C.coo_g.as<uint32_t>() + C.coo_n, C.coo_c.as<uint32_t>() + C.coo_n,
-                       c->ctr.as<unsigned long long>(), (uint32_t*)nullptr);
-    kt_end(c, tagB, 0);
+                       C.ws_ctr.as<unsigned long long>(), (uint32_t*)nullptr);
+    kt_end(c, tagB, 0, st);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 16, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    uint64_t n_new = c->h_ctr[0], n_emit = c->h_ctr[1];
+    HIPCHK(c, hipMemcpyAsync(C.h_ctr, C.ws_ctr.p, 16, hipMemcpyDeviceToHost, st));
+    return MIRGE_OK;
+}
+template <int KW>
+int collapse_finish(mirge_ctx* c, Class& C, const char* tagB) {
+    if (!C.pending) return MIRGE_OK;
+    C.pending = false;
+    if (C.pend_n == 0) { C.segs.push_back({C.pend_sample, C.coo_n, 0}); return MIRGE_OK; }
+    HIPCHK(c, hipStreamSynchronize(C.st));
+    uint64_t n_new = C.h_ctr[0], n_emit = C.h_ctr[1];
     ktime(c, tagB).bytes = n_new * (KW * 8 + 4) + n_emit * 4;
     if (C.gvalid && n_new) {
-        hipLaunchKernelGGL((k_gtable_insert<KW>), dim3((uint32_t)((n_new + 255) / 256)), dim3(256), 0, c->st,
+        hipLaunchKernelGGL((k_gtable_insert<KW>), dim3((uint32_t)((n_new + 255) / 256)), dim3(256), 0, C.st,
                            C.ukeys.as<uint64_t>(), (uint32_t)C.U, (uint32_t)(C.U + n_new), C.gslots.as<uint32_t>(), (uint32_t)(C.gcap - 1));
         HIPCHK(c, hipGetLastError());
     }
-    C.segs.push_back({sample, C.coo_n, n_emit});
+    C.segs.push_back({C.pend_sample, C.coo_n, n_emit});
     C.U += n_new; C.coo_n += n_emit;
     return MIRGE_OK;
+}
+
+// both classes of one sample: the 16-byte class on st, the 48-byte class on st2, side by side
+int collapse_both(mirge_ctx* c, const uint64_t* d16, uint64_t n16, const uint32_t* w16, const uint64_t* d48, uint64_t n48, const uint32_t* w48, int sample) {
+    int rc = fork_st2(c);                                  // the inputs were produced on st
+    if (!rc) rc = collapse_launch<2>(c, c->cls[0], d16, n16, sample, "collapse_local16", "collapse_emit16", w16);
+    if (!rc) rc = collapse_launch<6>(c, c->cls[1], d48, n48, sample, "collapse_local48", "collapse_emit48", w48);
+    if (rc) {                                              // a failed launch: drop whatever was queued
+        c->cls[0].pending = c->cls[1].pending = false;
+        (void)hipStreamSynchronize(c->st); (void)hipStreamSynchronize(c->st2);
+        return rc;
+    }
+    rc = collapse_finish<2>(c, c->cls[0], "collapse_emit16");
+    int r1 = collapse_finish<6>(c, c->cls[1], "collapse_emit48");
+    if (!rc) rc = r1;
+    if (!rc) rc = join_st2(c);
+    return rc;
 }
 
 int collapse_packed(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, uint64_t n48, int sample) {
@@ -349,8 +398,7 @@ int collapse_packed(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48
     hipEvent_t a, b;
     HIPCHK(c, hipEventCreate(&a)); HIPCHK(c, hipEventCreate(&b));
     HIPCHK(c, hipEventRecord(a, c->st));
-    int rc = collapse_class<2>(c, c->cls[0], (const uint64_t*)d16, n16, sample, "collapse_local16", "collapse_emit16");
-    if (!rc) rc = collapse_class<6>(c, c->cls[1], (const uint64_t*)d48, n48, sample, "collapse_local48", "collapse_emit48");
+    int rc = collapse_both(c, (const uint64_t*)d16, n16, nullptr, (const uint64_t*)d48, n48, nullptr, sample);
     if (!rc) {
         HIPCHK(c, hipEventRecord(b, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
@@ -684,10 +732,8 @@ int shard_import(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, u
     kt_clear(c, "collapse");
     uint64_t o16 = 0, o48 = 0;
     for (int s = 0; s < c->S && !rc; ++s) {
-        rc = collapse_class<2>(c, c->cls[0], c->stage16.as<uint64_t>() + o16 * 2, c16[(size_t)s], s, "collapse_local16", "collapse_emit16",
-                               c->sh_w[0].as<uint32_t>() + o16);
-        if (!rc) rc = collapse_class<6>(c, c->cls[1], c->stage48.as<uint64_t>() + o48 * 6, c48[(size_t)s], s, "collapse_local48", "collapse_emit48",
-                                        c->sh_w[1].as<uint32_t>() + o48);
+        rc = collapse_both(c, c->stage16.as<uint64_t>() + o16 * 2, c16[(size_t)s], c->sh_w[0].as<uint32_t>() + o16,
+                           c->stage48.as<uint64_t>() + o48 * 6, c48[(size_t)s], c->sh_w[1].as<uint32_t>() + o48, s);
         o16 += c16[(size_t)s]; o48 += c48[(size_t)s];
     }
     if (!rc) { HIPCHK(c, hipStreamSynchronize(c->st)); kt_resolve(c); }
@@ -697,12 +743,12 @@ int shard_import(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, u
 // ---- cascade + count vectors
 template <int KW, int RN>
 void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, int thr, int r) {
-    hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((C.U + MB - 1) / MB)), dim3(MB), 0, c->st,
+    hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((C.U + MB - 1) / MB)), dim3(MB), 0, C.st,
                        C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
-                       C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats.as<unsigned long long>() + (size_t)r * STAT_WORDS,
-                       r <= 1 ? (const uint32_t*)nullptr : C.act[(r + 1) & 1].as<uint32_t>(), C.act_n.as<unsigned long long>() + r,
+                       C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
+                       r <= 1 ? (const uint32_t*)nullptr : C.act[(r + 1) & 1].as<uint32_t>(), C.act_n + r,
                        (r >= 1 && r + 1 < c->n_rounds) ? C.act[r & 1].as<uint32_t>() : (uint32_t*)nullptr,
-                       C.act_n.as<unsigned long long>() + r + 1);   // round 1 keeps no list: nearly everything survives it
+                       C.act_n + r + 1);   // round 1 keeps no list: nearly everything survives it
 }
 
 // the round number is a template parameter only so that every round is its own kernel symbol in a
@@ -732,11 +778,10 @@ int counts_class(mirge_ctx* c, Class& C, int M) {
     for (auto& sg : C.segs) {
         if (!sg.count) continue;
         uint32_t grid = (uint32_t)std::min<uint64_t>(512, (sg.count + 255) / 256);
-        hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(256), 0, c->st, C.coo_g.as<uint32_t>() + sg.start,
+        hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(256), 0, C.st, C.coo_g.as<uint32_t>() + sg.start,
                            C.coo_c.as<uint32_t>() + sg.start, (uint32_t)sg.count, sg.sample, c->S, C.ukeys.as<uint64_t>(),
                            C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), M, 1, 5,
-                           c->d_quant.as<unsigned long long>(), c->d_iscan.as<unsigned long long>(),
-                           c->d_cat.as<unsigned long long>(), c->d_len.as<unsigned long long>(), c->d_tu.as<unsigned long long>());
+                           c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu);
     }
     HIPCHK(c, hipGetLastError());
     return MIRGE_OK;
@@ -753,61 +798,61 @@ int annotate(mirge_ctx* c) {
     }
     if (!c->libs[MIRGE_LIB_MIRNA].loaded) return fail(c, MIRGE_E_ARG, "mirna library not loaded");
     kt_clear(c, "match"); kt_clear(c, "counts");
+    // Round 1 walks the whole table and leaves every unique's annotation state behind (k_match_round<KW, 0>), so
+    // ann_round / ann_ref / ann_amb need no fill of their own.
     for (int k = 0; k < 2; ++k) {
         Class& C = c->cls[k];
         size_t U = std::max<uint64_t>(C.U, 1);
         HIPCHK(c, C.ann_round.ensure(U, false, 0, c->st));
         HIPCHK(c, C.ann_ref.ensure(U * 4, false, 0, c->st));
         HIPCHK(c, C.ann_amb.ensure(U, false, 0, c->st));
-        HIPCHK(c, hipMemsetAsync(C.ann_round.p, 0, U, c->st));
-        HIPCHK(c, hipMemsetAsync(C.ann_ref.p, 0xFF, U * 4, c->st));
-        HIPCHK(c, hipMemsetAsync(C.ann_amb.p, 0, U, c->st));
         HIPCHK(c, C.act[0].ensure(U * 4, false, 0, c->st));
         HIPCHK(c, C.act[1].ensure(U * 4, false, 0, c->st));
-        HIPCHK(c, C.act_n.ensure((MIRGE_MAX_ROUNDS + 1) * 8, false, 0, c->st));
-        HIPCHK(c, hipMemsetAsync(C.act_n.p, 0, (MIRGE_MAX_ROUNDS + 1) * 8, c->st));
     }
     int M = (int)c->libs[MIRGE_LIB_MIRNA].names.size(), S = c->S;
     size_t qn = std::max<size_t>((size_t)M * S, 1);
-    HIPCHK(c, c->d_stats.ensure(MIRGE_MAX_ROUNDS * STAT_WORDS * 8, false, 0, c->st));
-    HIPCHK(c, c->d_quant.ensure(qn * 8, false, 0, c->st));
-    HIPCHK(c, c->d_iscan.ensure(qn * 8, false, 0, c->st));
-    HIPCHK(c, c->d_cat.ensure((size_t)5 * S * 8, false, 0, c->st));
-    HIPCHK(c, c->d_len.ensure((size_t)128 * S * 8, false, 0, c->st));
-    HIPCHK(c, c->d_tu.ensure((size_t)S * 8, false, 0, c->st));
-    HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, MIRGE_MAX_ROUNDS * STAT_WORDS * 8, c->st));
-    HIPCHK(c, hipMemsetAsync(c->d_quant.p, 0, qn * 8, c->st));
-    HIPCHK(c, hipMemsetAsync(c->d_iscan.p, 0, qn * 8, c->st));
-    HIPCHK(c, hipMemsetAsync(c->d_cat.p, 0, (size_t)5 * S * 8, c->st));
-    HIPCHK(c, hipMemsetAsync(c->d_len.p, 0, (size_t)128 * S * 8, c->st));
-    HIPCHK(c, hipMemsetAsync(c->d_tu.p, 0, (size_t)S * 8, c->st));
+    const size_t w_stats = MIRGE_MAX_ROUNDS * STAT_WORDS, w_cat = (size_t)5 * S, w_len = (size_t)128 * S, w_tu = (size_t)S;
+    const size_t w_out = w_stats + 2 * qn + w_cat + w_len + w_tu, w_all = w_out + 2 * (MIRGE_MAX_ROUNDS + 1);
+    HIPCHK(c, c->state.ensure(w_all * 8, false, 0, c->st));
+    if (c->h_state_cap < w_out) {
+        if (c->h_state) (void)hipHostFree(c->h_state);
+        c->h_state = nullptr; c->h_state_cap = 0;
+        HIPCHK(c, hipHostMalloc((void**)&c->h_state, w_out * 8));
+        c->h_state_cap = w_out;
+    }
+    c->d_stats = c->state.as<unsigned long long>();
+    c->d_quant = c->d_stats + w_stats; c->d_iscan = c->d_quant + qn; c->d_cat = c->d_iscan + qn;
+    c->d_len = c->d_cat + w_cat; c->d_tu = c->d_len + w_len;
+    c->cls[0].act_n = c->d_tu + w_tu; c->cls[1].act_n = c->cls[0].act_n + (MIRGE_MAX_ROUNDS + 1);
+    HIPCHK(c, hipMemsetAsync(c->state.p, 0, w_all * 8, c->st));
     hipEvent_t e0, e1, e2;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
     HIPCHK(c, hipEventRecord(e0, c->st));
+    // the 48-byte class (reads with N or longer than 56 nt: a fraction of a percent) runs its cascade on st2 beside
+    // the 16-byte class; the two meet only in atomically updated counters.  Kernel times are those of the 16-byte class.
+    { int rc = fork_st2(c); if (rc) return rc; }
     for (int r = 0; r < c->n_rounds; ++r) {
         kt_begin(c, kRoundNames[r]);
         int rc = annotate_class<2>(c, c->cls[0], r, c->rounds[r]);
+        kt_end(c, kRoundNames[r], 0);
         if (!rc) rc = annotate_class<6>(c, c->cls[1], r, c->rounds[r]);
         if (rc) return rc;
-        kt_end(c, kRoundNames[r], 0);
     }
     HIPCHK(c, hipEventRecord(e1, c->st));
     kt_begin(c, "counts");
     int rc = counts_class<2>(c, c->cls[0], M);
+    kt_end(c, "counts", (c->cls[0].coo_n + c->cls[1].coo_n) * 8 + (uint64_t)16 * M * S);
     if (!rc) rc = counts_class<6>(c, c->cls[1], M);
     if (rc) return rc;
-    kt_end(c, "counts", (c->cls[0].coo_n + c->cls[1].coo_n) * 8 + (uint64_t)16 * M * S);
+    { int rj = join_st2(c); if (rj) return rj; }
     HIPCHK(c, hipEventRecord(e2, c->st));
-    c->h_quant.assign(qn, 0); c->h_iscan.assign(qn, 0); c->h_cat.assign((size_t)5 * S, 0);
-    c->h_len.assign((size_t)128 * S, 0); c->h_tu.assign((size_t)S, 0);
-    std::vector<uint64_t> hraw(MIRGE_MAX_ROUNDS * STAT_WORDS);
-    HIPCHK(c, hipMemcpyAsync(hraw.data(), c->d_stats.p, hraw.size() * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(c->h_quant.data(), c->d_quant.p, (size_t)M * S * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(c->h_iscan.data(), c->d_iscan.p, (size_t)M * S * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(c->h_cat.data(), c->d_cat.p, (size_t)5 * S * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(c->h_len.data(), c->d_len.p, (size_t)128 * S * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(c->h_tu.data(), c->d_tu.p, (size_t)S * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->h_state, c->state.p, w_out * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    const unsigned long long* hraw = c->h_state;
+    c->h_quant.assign(hraw + w_stats, hraw + w_stats + qn); c->h_iscan.assign(hraw + w_stats + qn, hraw + w_stats + 2 * qn);
+    c->h_cat.assign(hraw + w_stats + 2 * qn, hraw + w_stats + 2 * qn + w_cat);
+    c->h_len.assign(hraw + w_stats + 2 * qn + w_cat, hraw + w_stats + 2 * qn + w_cat + w_len);
+    c->h_tu.assign(hraw + w_out - w_tu, hraw + w_out);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1); c->annotate_ms = ms;
     (void)hipEventElapsedTime(&ms, e1, e2); c->counts_ms = ms;
@@ -910,9 +955,14 @@ mirge_ctx* mirge_open(const char* species_dir, int32_t n_samples, int32_t device
     mirge_ctx* c = new mirge_ctx();
     c->device = device; c->S = n_samples;
     c->cls[0].KW = 2; c->cls[1].KW = 6;
-    if (hipStreamCreate(&c->st) != hipSuccess || hipHostMalloc((void**)&c->h_ctr, 128) != hipSuccess) {
+    if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->st2) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_ctr, 128 + 64) != hipSuccess) {
         fail(nullptr, MIRGE_E_HIP, "cannot create stream / pinned buffer"); delete c; return nullptr;
     }
+    c->cls[0].st = c->st; c->cls[1].st = c->st2;
+    c->cls[0].h_ctr = c->h_ctr + 16; c->cls[1].h_ctr = c->h_ctr + 20;      // inside the pinned block
     // miRge.pl:326, 333-339
     static const mirge_round def[5] = {{MIRGE_LIB_MIRNA, 26, 0, 0, 0, 28, 0, 2}, {MIRGE_LIB_HAIRPIN, 0, 25, 0, 0, 28, 1, 2},
                                        {MIRGE_LIB_OTHER, 0, 0, 0, 0, 28, 1, 2},  {MIRGE_LIB_MRNA, 0, 0, 0, 0, 28, 0, 2},
@@ -943,13 +993,18 @@ void mirge_close(mirge_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->st) (void)hipStreamSynchronize(c->st);
+    if (c->st2) (void)hipStreamSynchronize(c->st2);
     for (auto& L : c->libs) L.release();
     for (auto& C : c->cls) C.release();
-    DevBuf* ws[] = {&c->lslots, &c->cnt, &c->cnt0, &c->rep, &c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
-                    &c->fq_raw, &c->fq_seg, &c->fq_segb, &c->fq_start, &c->fq_qstart, &c->fq_qend, &c->sh_ctr, &c->sh_w[0], &c->sh_w[1], &c->hist, &c->d_stats, &c->d_quant, &c->d_iscan, &c->d_cat, &c->d_len, &c->d_tu};
+    DevBuf* ws[] = {&c->rep, &c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
+                    &c->fq_raw, &c->fq_seg, &c->fq_segb, &c->fq_start, &c->fq_qstart, &c->fq_qend, &c->sh_ctr, &c->sh_w[0], &c->sh_w[1], &c->hist, &c->state};
     for (auto* b : ws) b->release();
     for (auto& k : c->kt) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->st2) (void)hipStreamDestroy(c->st2);
     if (c->fq_pin) (void)hipHostFree(c->fq_pin);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
