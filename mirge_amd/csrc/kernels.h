@@ -499,6 +499,15 @@ template <class Vec> inline void build_ref_lut(const uint32_t* ref_start, uint32
 // every read of a round, so the piece loop is wave-uniform.
 MG_HD int round_np(const RoundDev& P) { return (P.seedmm < P.maxmm ? P.seedmm : P.maxmm) + 1; }
 MG_HD bool round_whole(const RoundDev& P) { return round_np(P) == P.maxmm + 1; }
+// Pigeonhole, the other way round: once pieces 0 .. p-1 of the SEED have been looked up, every alignment with fewer
+// than p seed mismatches is among their candidates (one of those p pieces is free of mismatches).  So if the best
+// alignment known by then already has < p seed mismatches, piece p can only turn up worse strata, which
+// `--best --strata` drops: its lookups are skipped.  (Not for pieces cut from the whole read: there the count that
+// is bounded is the total, not the stratum.)  `score` = best hit_score so far, 0 = none.
+MG_HD bool piece_needed(const RoundDev& P, int p, uint64_t score) {
+    if (p == 0 || score == 0 || round_whole(P)) return true;
+    return 4 - (int)(score >> 36) >= p;
+}
 // floor(x * p / np) for x <= 4095, p <= np <= 4, without an integer division
 MG_HD int piece_cut(int x, int p, int np) { return (int)(((uint32_t)(x * p) * (uint32_t)(65536 / np + 1)) >> 16); }
 
@@ -680,12 +689,13 @@ __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, 
     if (!Q.ok) return false;
     const int np = round_np(P);
     uint64_t score = 0, kmax = 0, kmin = 0;
-    for (int fw = 1; fw >= 0; --fw) {
-        const Oriented<SW>& o = Q.q[fw];
-        Strand<SW, HASN> S;
-        strand_setup<SW, HASN>(o, fw, Q.l, Q.s, P, S);
-        if (!S.ok) continue;
-        for (int p = 0; p < np; ++p) {
+    for (int p = 0; p < np; ++p) {
+        if (!piece_needed(P, p, score)) break;                  // as the kernel: decided once per piece, before either strand
+        for (int fw = 1; fw >= 0; --fw) {
+            const Oriented<SW>& o = Q.q[fw];
+            Strand<SW, HASN> S;
+            strand_setup<SW, HASN>(o, fw, Q.l, Q.s, P, S);
+            if (!S.ok) continue;
             int qs; uint64_t b0, b1;
             if (!piece_buckets_fwd<SW, HASN>(Q.q[1], Q.l, L.kb, fw, piece_cut(Q.span, p, np), piece_cut(Q.span, p + 1, np), qs, b0, b1)) continue;
             PieceAl A;
@@ -831,11 +841,13 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     for (int p = 0; p < np; ++p) {
         const int ps = piece_cut(Q.span, p, np), pe = piece_cut(Q.span, p + 1, np);
         uint32_t lo[2], hi[2]; int qs[2];
+        // what this thread checked itself is in s_best[tid] by now (queued lists are not: they can only add hits)
+        const bool need = p == 0 || piece_needed(P, p, s_best[tid]);
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             uint64_t b0 = 0, b1 = 0;
             lo[f] = 0; hi[f] = 0; qs[f] = 0;
-            if (sok[f] && piece_buckets_fwd<SW, HASN>(Q.q[1], Q.l, L.kb, f, ps, pe, qs[f], b0, b1)) koff_range(L, b0, b1, lo[f], hi[f]);
+            if (need && sok[f] && piece_buckets_fwd<SW, HASN>(Q.q[1], Q.l, L.kb, f, ps, pe, qs[f], b0, b1)) koff_range(L, b0, b1, lo[f], hi[f]);
         }
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
