@@ -885,19 +885,22 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         if (lane == 0) e0 = atomicAdd(&s_next, (uint32_t)MG_PF);
         e0 = __shfl(e0, 0);
         if (e0 >= qn) break;
-        PreAl R[MG_PF]; uint64_t pv[MG_PF]; uint32_t lo[MG_PF], hi[MG_PF];
+        // while the loads are in flight a list costs four registers (bounds + the loaded word); the prepared piece is
+        // read back from LDS (a broadcast) only when its words have arrived: no spills at 80 VGPRs
+        uint64_t pv[MG_PF]; uint32_t lo[MG_PF], hi[MG_PF];
 #pragma unroll
         for (int j = 0; j < MG_PF; ++j) {
             const uint32_t e = e0 + j < qn ? e0 + j : qn - 1;       // clamp: a valid entry, ignored below
-            R[j] = pre_of(s_queue[e]);
             lo[j] = s_queue[e].lo; hi[j] = e0 + j < qn ? s_queue[e].hi : lo[j];
             const uint32_t c = lo[j] + lane;
             pv[j] = c < hi[j] ? L.kpre[c] : 0ull;
         }
 #pragma unroll
         for (int j = 0; j < MG_PF; ++j) {
+            if (e0 + j >= qn) break;
             uint32_t c = lo[j] + lane;
-            bool pass = c < hi[j] && pre_pass(R[j], pv[j], P.maxmm);
+            const PreAl Rj = pre_of(s_queue[e0 + j]);
+            bool pass = c < hi[j] && pre_pass(Rj, pv[j], P.maxmm);
             for (;;) {
                 if (pass) {
                     const PieceAl A = s_queue[e0 + j];
@@ -909,7 +912,7 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
                 }
                 c += 64;
                 if (!__any(c < hi[j])) break;                   // lists longer than 64: the remaining strides, one load each
-                pass = c < hi[j] && pre_pass(R[j], L.kpre[c < hi[j] ? c : lo[j]], P.maxmm);
+                pass = c < hi[j] && pre_pass(Rj, L.kpre[c < hi[j] ? c : lo[j]], P.maxmm);
             }
         }
     }
