@@ -90,7 +90,9 @@ int32_t     mirge_set_rounds(mirge_ctx*, int32_t n_rounds, const mirge_round* ro
 /* The read loop of miRge.pl:299-307 on the device: the file streams into HBM as raw bytes (reader threads ->
  * pinned ring -> DMA) and is split into records there (four lines each; key = line 2 minus its "\n", nothing
  * else stripped; a record cut short by the end of the file still counts, with an empty sequence if line 2 is
- * missing).  n_reads (nullable) receives the number of records. */
+ * missing).  n_reads (nullable) receives the number of records.  A gzip file (magic 1f 8b; "fastq or fastq.gz",
+ * miRge.pl:1092) is inflated on the host, slot by slot, on its way into the ring; the same holds for
+ * mirge_collapse_raw_fastq. */
 int32_t     mirge_collapse_fastq(mirge_ctx*, const char* trimmed_fastq, int32_t sample, uint64_t* n_reads);
 /* The same for FASTQ text held in host memory / already resident in HBM (d_data 16-byte aligned; no bytes at or
  * beyond `size` are interpreted, and none beyond the 16-byte unit that holds byte size-1 are touched). */

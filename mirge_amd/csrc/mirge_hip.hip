@@ -21,6 +21,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <zlib.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -575,6 +576,65 @@ int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t la
     return collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
 }
 
+// gzip file -> HBM (the reference takes fastq or fastq.gz, miRge.pl:1092; cutadapt's reader inflates it inside
+// trim_file.py:123).  A gzip stream inflates serially: one thread fills the pinned ring slot by slot while the DMA of
+// the previous slots runs; the device buffer starts at the size the gzip trailer states and grows if the file holds more.
+int fastq_gz_to_hbm(mirge_ctx* c, const char* path, uint64_t csize, uint64_t* size_out, uint8_t* last_out) {
+    auto t0 = std::chrono::steady_clock::now();
+    uint64_t hint = csize * 4;
+    if (FILE* f = fopen(path, "rb")) {               // ISIZE: inflated size mod 2^32 of the last member
+        unsigned char t[4];
+        if (csize >= 18 && fseek(f, -4, SEEK_END) == 0 && fread(t, 1, 4, f) == 4) {
+            uint64_t isz = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+            if (isz > hint) hint = isz;
+        }
+        fclose(f);
+    }
+    gzFile g = gzopen(path, "rb");
+    if (!g) return fail(c, MIRGE_E_IO, std::string("cannot open ") + path);
+    (void)gzbuffer(g, 1u << 20);
+    if (!c->fq_pin && hipHostMalloc((void**)&c->fq_pin, FQ_SLOTS * FQ_SLOT_BYTES) != hipSuccess) {
+        gzclose(g); return fail(c, MIRGE_E_HIP, "cannot allocate the pinned staging ring");
+    }
+    hipError_t he = c->fq_raw.ensure(hint + 256, false, 0, c->st);
+    hipEvent_t ev[FQ_SLOTS];
+    for (auto& e : ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    int rc = he == hipSuccess ? MIRGE_OK : fail(c, MIRGE_E_HIP, std::string("FASTQ buffer: ") + hipGetErrorString(he));
+    uint64_t off = 0;
+    *last_out = '\n';
+    for (uint64_t i = 0; rc == MIRGE_OK; ++i) {
+        const int slot = (int)(i % FQ_SLOTS);
+        if (i >= (uint64_t)FQ_SLOTS && hipEventSynchronize(ev[slot]) != hipSuccess) { rc = fail(c, MIRGE_E_HIP, "FASTQ upload failed"); break; }
+        uint8_t* dst = c->fq_pin + (size_t)slot * FQ_SLOT_BYTES;
+        size_t got = 0;
+        while (got < FQ_SLOT_BYTES) {
+            int r = gzread(g, dst + got, (unsigned)std::min<size_t>(FQ_SLOT_BYTES - got, 1u << 30));
+            if (r < 0) { int en = 0; const char* m = gzerror(g, &en); rc = fail(c, MIRGE_E_IO, std::string(path) + ": " + (m ? m : "gzip error")); break; }
+            if (r == 0) break;
+            got += (size_t)r;
+        }
+        if (rc || got == 0) break;
+        he = c->fq_raw.ensure(off + got + 256, true, off, c->st);       // grows by half when the trailer understated the size
+        if (he == hipSuccess) he = hipMemcpyAsync(c->fq_raw.as<uint8_t>() + off, dst, got, hipMemcpyHostToDevice, c->st);
+        if (he == hipSuccess) he = hipEventRecord(ev[slot], c->st);
+        if (he != hipSuccess) { rc = fail(c, MIRGE_E_HIP, std::string("FASTQ upload: ") + hipGetErrorString(he)); break; }
+        *last_out = dst[got - 1];
+        off += got;
+        if (got < FQ_SLOT_BYTES) break;
+    }
+    if (rc == MIRGE_OK) {
+        int en = 0; (void)gzerror(g, &en);
+        if (en != Z_OK && en != Z_STREAM_END) rc = fail(c, MIRGE_E_IO, std::string(path) + ": corrupt or truncated gzip stream");
+    }
+    gzclose(g);
+    hipError_t e = hipStreamSynchronize(c->st);
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    if (rc == MIRGE_OK && e != hipSuccess) rc = fail(c, MIRGE_E_HIP, std::string("FASTQ upload: ") + hipGetErrorString(e));
+    *size_out = off;
+    c->ingest_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
 // file -> HBM: reader threads pread() slices into a pinned ring, this thread queues one DMA per slice in file order
 int fastq_file_to_hbm(mirge_ctx* c, const char* path, uint64_t* size_out, uint8_t* last_out) {
     int fd = open(path, O_RDONLY);
@@ -582,6 +642,10 @@ int fastq_file_to_hbm(mirge_ctx* c, const char* path, uint64_t* size_out, uint8_
     struct stat sb;
     if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { close(fd); return fail(c, MIRGE_E_IO, std::string(path) + " is not a regular file"); }
     const uint64_t size = (uint64_t)sb.st_size;
+    {   // gzip magic?
+        unsigned char mg[2] = {0, 0};
+        if (size >= 2 && pread(fd, mg, 2, 0) == 2 && mg[0] == 0x1f && mg[1] == 0x8b) { close(fd); return fastq_gz_to_hbm(c, path, size, size_out, last_out); }
+    }
     *size_out = size; *last_out = '\n';
     auto t0 = std::chrono::steady_clock::now();
     hipError_t he = c->fq_raw.ensure(size + 256, false, 0, c->st);

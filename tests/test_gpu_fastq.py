@@ -109,3 +109,43 @@ def test_multi_window_path(ctx, monkeypatch):
     ctx.reset()
     assert ctx.collapse_fastq_mem(data, 0) == len(perl_records(data))
     assert table(ctx) == want(data)
+
+
+def test_gzip_files(ctx, tmp_path):
+    """fastq.gz (miRge.pl:1092; cutadapt's reader inflates inside trim_file.py:123): single member, several members
+    back to back (the trailer then understates the size: the device buffer grows), a file larger than the 16 MB ring
+    slots, empty content, and a truncated stream (loud failure)."""
+    import gzip
+    rng = np.random.default_rng(11)
+    small = random_fastq(rng, 4000, maxlen=60)
+    pool = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(l)).tolist()) for l in rng.integers(16, 48, size=2000)]
+    big = b"".join(b"@read%d\n%s\n+\n%s\n" % (i, pool[j], b"I" * len(pool[j])) for i, j in enumerate(rng.integers(0, len(pool), size=450000)))
+    assert len(big) > (32 << 20)          # more than two 16 MB ring slots
+    cases = {"one.fastq.gz": (gzip.compress(small, 6), small),
+             "multi.fastq.gz": (gzip.compress(small[:1000], 1) + gzip.compress(small[1000:], 9) + gzip.compress(b""), small),
+             "big.fastq.gz": (gzip.compress(big, 1), big),
+             "empty.fastq.gz": (gzip.compress(b""), b"")}
+    for name, (blob, data) in cases.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        ctx.reset()
+        assert ctx.collapse_fastq(str(p), 0) == len(perl_records(data)), name
+        assert table(ctx) == want(data), name
+    p = tmp_path / "cut.fastq.gz"
+    p.write_bytes(cases["one.fastq.gz"][0][:-200])
+    ctx.reset()
+    with pytest.raises(capi.MirgeError) as e:
+        ctx.collapse_fastq(str(p), 0)
+    assert e.value.code == capi.MIRGE_E_IO
+    # raw reads (trimming path) from a gzip file give what the plain file gives
+    from mirge_amd import synth
+    libs, _ = synth.make_libraries(synth.Profile.tiny(), synth.BASE_SEED + 3)
+    seqs, lens = synth.make_reads(libs, 20000, synth.BASE_SEED + 5)
+    plain = tmp_path / "raw.fastq"
+    synth.write_raw_fastq_fast(str(plain), seqs, lens, synth.BASE_SEED + 6)
+    (tmp_path / "raw.fastq.gz").write_bytes(gzip.compress(plain.read_bytes(), 1))
+    ctx.reset()
+    a = ctx.collapse_raw_fastq(str(plain), 0, "illumina"); ta = table(ctx)
+    ctx.reset()
+    b = ctx.collapse_raw_fastq(str(tmp_path / "raw.fastq.gz"), 0, "illumina")
+    assert tuple(a) == tuple(b) and table(ctx) == ta and a[0] == 20000
