@@ -58,7 +58,8 @@ typedef struct {
 
 /* Opens a context on HIP device `device`.  species_dir = miRge.seqLibs/<species>
  * (miRge.pl:92): the four libraries are read from <species_dir>/{mirna,hairpin,
- * other,mrna}.fa (FASTA beside the .ebwt files; an .ebwt reader is future work)
+ * other,mrna}.fa (FASTA beside the .ebwt files) or, where there is none, out of
+ * the bowtie index itself (<lib>.1/.3/.4.ebwt; layout unvalidated, see ebwt.h)
  * and their k-mer seed indexes are built on the device -- the step the
  * reference pays as a bowtie process start + index load in every round
  * (miRge.pl:353).  species_dir may be NULL: load libraries with
@@ -74,6 +75,11 @@ int32_t     mirge_reset(mirge_ctx*, int32_t n_samples);
 /* ---- libraries (replaces the per-round index load inside bowtie, and
  *      `bowtie-inspect -n`, miRge.pl:457-463) ------------------------------ */
 int32_t     mirge_load_library_fasta(mirge_ctx*, int32_t lib, const char* fasta_path);
+/* The same from a bowtie 1 index, <ebwt_base>.{1,3,4}.ebwt -- the files miRge.pl:92-97 points bowtie at and
+ * checks at :189-192: names as `bowtie-inspect -n` prints them (:457), sequences with N for ambiguous
+ * stretches.  The on-disk layout is restated from memory of bowtie 1.1.1 (absent here) and could not be
+ * checked against a real index: every size it implies is verified and a mismatch fails with MIRGE_E_FORMAT. */
+int32_t     mirge_load_library_ebwt(mirge_ctx*, int32_t lib, const char* ebwt_base);
 /* names: n NUL-terminated header lines back to back; seqs: concatenated ASCII; offs[n+1]. */
 int32_t     mirge_load_library_mem(mirge_ctx*, int32_t lib, int32_t n, const char* names,
                                    const char* seqs, const uint64_t* offs);

@@ -18,7 +18,7 @@ MAX_ROUNDS = 8
 MAX_READ_LEN = 124
 
 EXPORTS = [
-    "mirge_open", "mirge_close", "mirge_last_error", "mirge_reset", "mirge_load_library_fasta",
+    "mirge_open", "mirge_close", "mirge_last_error", "mirge_reset", "mirge_load_library_fasta", "mirge_load_library_ebwt",
     "mirge_load_library_mem", "mirge_lib_size", "mirge_lib_name", "mirge_lib_short_name", "mirge_set_rounds",
     "mirge_collapse_raw_fastq", "mirge_collapse_raw_fastq_mem",
     "mirge_shard_export_sizes", "mirge_shard_export", "mirge_shard_import",
@@ -66,6 +66,7 @@ def load():
     L.mirge_last_error.restype = C.c_char_p; L.mirge_last_error.argtypes = [vp]
     L.mirge_reset.argtypes = [vp, i32]
     L.mirge_load_library_fasta.argtypes = [vp, i32, C.c_char_p]
+    L.mirge_load_library_ebwt.argtypes = [vp, i32, C.c_char_p]
     L.mirge_load_library_mem.argtypes = [vp, i32, i32, C.c_char_p, vp, vp]
     L.mirge_lib_size.argtypes = [vp, i32]
     L.mirge_lib_name.restype = C.c_char_p; L.mirge_lib_name.argtypes = [vp, i32, i32]
@@ -142,6 +143,9 @@ class Context:
 
     def load_library_fasta(self, lib, path):
         self._chk(self.L.mirge_load_library_fasta(self.h, lib, path.encode()))
+
+    def load_library_ebwt(self, lib, base):
+        self._chk(self.L.mirge_load_library_ebwt(self.h, lib, base.encode()))
 
     def lib_size(self, lib):
         return self._chk(self.L.mirge_lib_size(self.h, lib))

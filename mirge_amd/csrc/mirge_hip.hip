@@ -7,6 +7,7 @@
 #include "fastq.h"
 #include "shard.h"
 #include "trim.h"
+#include "ebwt.h"
 
 #include <algorithm>
 #include <atomic>
@@ -296,6 +297,13 @@ int load_fasta(mirge_ctx* c, int lib, const char* path) {
         i = e + 1;
     }
     offs.push_back(seqs.size());
+    return load_library(c, lib, std::move(names), seqs.data(), offs.data());
+}
+
+// a library out of a bowtie 1 index (ebwt.h: layout unvalidated, every implied size cross-checked)
+int load_ebwt(mirge_ctx* c, int lib, const std::string& base) {
+    std::vector<std::string> names; std::string seqs; std::vector<uint64_t> offs; std::string err;
+    if (ebwt_extract(base, names, seqs, offs, err) != 0) return fail(c, MIRGE_E_FORMAT, err);
     return load_library(c, lib, std::move(names), seqs.data(), offs.data());
 }
 
@@ -1043,8 +1051,15 @@ mirge_ctx* mirge_open(const char* species_dir, int32_t n_samples, int32_t device
             FILE* f = fopen(path.c_str(), "rb");
             if (!f) { path = base + ".fasta"; f = fopen(path.c_str(), "rb"); }
             if (!f) {
-                fail(nullptr, MIRGE_E_IO, "cannot find " + base + ".fa (the sequences must sit beside the .ebwt files)");
-                mirge_close(c); return nullptr;
+                // no FASTA beside the index: take the sequences out of the bowtie index itself
+                FILE* e = fopen((base + ".3.ebwt").c_str(), "rb");
+                if (!e) {
+                    fail(nullptr, MIRGE_E_IO, "cannot find " + base + ".fa or " + base + ".{1,3,4}.ebwt");
+                    mirge_close(c); return nullptr;
+                }
+                fclose(e);
+                if (load_ebwt(c, l, base) != MIRGE_OK) { g_open_error = c->err; mirge_close(c); return nullptr; }
+                continue;
             }
             fclose(f);
             if (load_fasta(c, l, path.c_str()) != MIRGE_OK) { g_open_error = c->err; mirge_close(c); return nullptr; }
@@ -1082,6 +1097,12 @@ int32_t mirge_reset(mirge_ctx* c, int32_t n_samples) {
     for (auto& C : c->cls) C.reset();
     c->annotated = false; c->counts_valid = false; c->host_valid = false;
     return MIRGE_OK;
+}
+
+int32_t mirge_load_library_ebwt(mirge_ctx* c, int32_t lib, const char* ebwt_base) {
+    if (!c || !ebwt_base) return MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return load_ebwt(c, lib, ebwt_base);
 }
 
 int32_t mirge_load_library_fasta(mirge_ctx* c, int32_t lib, const char* path) {

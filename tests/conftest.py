@@ -26,7 +26,8 @@ def hostsim():
     d = os.path.join(ROOT, "tests", "hostsim")
     so = os.path.join(d, "libhostsim.so")
     srcs = [os.path.join(d, "hostsim.hip"), os.path.join(ROOT, "mirge_amd", "csrc", "kernels.h"),
-            os.path.join(ROOT, "mirge_amd", "csrc", "keys.h"), os.path.join(ROOT, "mirge_amd", "csrc", "fastq.h"), os.path.join(ROOT, "mirge_amd", "csrc", "trim.h")]
+            os.path.join(ROOT, "mirge_amd", "csrc", "keys.h"), os.path.join(ROOT, "mirge_amd", "csrc", "fastq.h"), os.path.join(ROOT, "mirge_amd", "csrc", "trim.h"),
+            os.path.join(ROOT, "mirge_amd", "csrc", "ebwt.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, srcs[0]])
     L = C.CDLL(so)
@@ -41,6 +42,8 @@ def hostsim():
     L.sim_trim_fastq.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.sim_count_newlines.restype = C.c_uint64
     L.sim_count_newlines.argtypes = [C.c_void_p, C.c_uint64]
+    L.sim_ebwt_extract.restype = C.c_int64
+    L.sim_ebwt_extract.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
     L.sim_key_hash.restype = C.c_uint32
     L.sim_key_hash.argtypes = [C.c_void_p, C.c_int32]
     return L

@@ -5,6 +5,7 @@
 #include "../../mirge_amd/csrc/kernels.h"
 #include "../../mirge_amd/csrc/fastq.h"
 #include "../../mirge_amd/csrc/trim.h"
+#include "../../mirge_amd/csrc/ebwt.h"
 #include <algorithm>
 #include <vector>
 #include <cstring>
@@ -172,4 +173,19 @@ uint64_t sim_count_newlines(const uint8_t* data, uint64_t size) {
 
 uint32_t sim_key_hash(const uint64_t* key, int32_t kw) { return kw == 2 ? key_hash<2>(key) : key_hash<6>(key); }
 
+
+// ebwt.h on the host: names ('\n'-joined), sequences and offsets of <base>.{1,3,4}.ebwt.  Returns the number of
+// references, or -(error code) with the message in names_out.  Capacities in bytes / entries.
+int64_t sim_ebwt_extract(const char* base, char* names_out, uint64_t names_cap, char* seqs_out, uint64_t seqs_cap, uint64_t* offs_out, uint64_t offs_cap) {
+    std::vector<std::string> names; std::string seqs, err; std::vector<uint64_t> offs;
+    int rc = ebwt_extract(base, names, seqs, offs, err);
+    if (rc) { snprintf(names_out, (size_t)names_cap, "%s", err.c_str()); return -rc; }
+    std::string joined;
+    for (size_t i = 0; i < names.size(); ++i) { if (i) joined.push_back('\n'); joined += names[i]; }
+    if (joined.size() + 1 > names_cap || seqs.size() > seqs_cap || offs.size() > offs_cap) return -100;
+    memcpy(names_out, joined.c_str(), joined.size() + 1);
+    memcpy(seqs_out, seqs.data(), seqs.size());
+    for (size_t i = 0; i < offs.size(); ++i) offs_out[i] = offs[i];
+    return (int64_t)names.size();
+}
 }

@@ -267,3 +267,31 @@ def test_unique_table_merge_across_logical_shards(world):
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("name", util.golden_cases())
+def test_golden_tables_from_ebwt_only_species_dir(tmp_path, name):
+    """A seqLibs directory that holds only bowtie indexes (no FASTA): the libraries come out of <lib>.{1,3,4}.ebwt
+    (mirge_amd/csrc/ebwt.h; layout unvalidated against a real bowtie-build, written here by tests/ebwt_writer.py) and
+    the run reproduces the reference's tables as the FASTA-backed run does."""
+    import os
+    import shutil
+    from tests.ebwt_writer import write_ebwt
+    case = util.golden_case(name)
+    sp = tmp_path / "species"
+    sp.mkdir()
+    for lib in ("mirna", "hairpin", "other", "mrna"):
+        names, seqs = [], []
+        for line in open(os.path.join(case["species"], lib + ".fa")).read().split("\n"):
+            if line.startswith(">"):
+                names.append(line[1:]); seqs.append("")
+            elif names:
+                seqs[-1] += line.strip()
+        write_ebwt(str(sp / lib), names, seqs)
+    if os.path.exists(os.path.join(case["species"], "merges.csv")):
+        shutil.copy(os.path.join(case["species"], "merges.csv"), sp / "merges.csv")
+    run = MirgeRun(str(sp), case["fastqs"], case["names"])
+    out = str(tmp_path / "out")
+    run.run(out)
+    util.check_run_against_golden(run, case, out)
+    run.ctx.close()

@@ -10,12 +10,13 @@
 //                           a read wins
 //   miRge.pl:409-413        stderr: "reads processed: <n>" and "reads with at least one reported alignment: <n>"
 //   miRge.pl:457-459        <exe>-inspect -n <ebwt_base>: one reference name (whole header) per line
-// The sequences are read from <ebwt_base>.fa beside the .ebwt files.  One line is printed per aligned read:
+// The sequences are read from <ebwt_base>.fa beside the .ebwt files, else out of <ebwt_base>.{1,3,4}.ebwt.  One line is printed per aligned read:
 // the representative of its best stratum (the line miRge would keep); columns other than 0 and 2 are
 // placeholders (miRge ignores them; column 1 is stored and never used).
 //
 // This is the slow way in: one process start, one library load and one index build per round, as with
 // bowtie itself.  The fast way is the in-process C ABI (include/mirge_hip.h, perl/MirgeHip.xs).
+#include "../mirge_amd/csrc/ebwt.h"
 #include "../include/mirge_hip.h"
 #include <cstdio>
 #include <cstdlib>
@@ -65,8 +66,12 @@ int main(int argc, char** argv) {
     if (!pos[0]) { fprintf(stderr, "mirge-bowtie: no index basename given\n"); return 1; }
     Fasta lib;
     if (!read_fasta(std::string(pos[0]) + ".fa", lib) && !read_fasta(std::string(pos[0]) + ".fasta", lib)) {
-        fprintf(stderr, "mirge-bowtie: cannot read %s.fa (the sequences must sit beside the .ebwt files)\n", pos[0]);
-        return 1;
+        // no FASTA beside the index: the sequences come out of the bowtie index itself (ebwt.h; layout unvalidated)
+        std::string err;
+        if (mg::ebwt_extract(pos[0], lib.names, lib.seqs, lib.offs, err) != 0) {
+            fprintf(stderr, "mirge-bowtie: cannot read %s.fa, and: %s\n", pos[0], err.c_str());
+            return 1;
+        }
     }
     if (inspect) { for (auto& nm : lib.names) printf("%s\n", nm.c_str()); return 0; }
     if (!pos[1]) { fprintf(stderr, "mirge-bowtie: no reads file given\n"); return 1; }
