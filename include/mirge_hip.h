@@ -182,6 +182,17 @@ int32_t     mirge_export_uniques(mirge_ctx*, char* seqs, uint32_t stride, uint8_
 uint64_t    mirge_n_counts(const mirge_ctx*);
 int32_t     mirge_export_counts(mirge_ctx*, uint64_t* uid, uint32_t* sample, uint32_t* count);
 
+/* ---- tables ------------------------------------------------------------- */
+/* The host tail of a run without Perl (batch mode): the bookkeeping of summarize (miRge.pl:457-478), miRNAmerge
+ * (:496-524; merges_csv may be NULL or missing, as in :521-523), filter (:526-554) and the four tables of
+ * writeDataToCSV -- mapped.csv (:702-752), unmapped.csv (:845-863), miR.Counts.csv (:865-885), miR.RPM.csv
+ * (:887-906) -- written into output_dir with the reference's formats (bytewise-sorted names, empty miRNAtotal
+ * cell for a sample without miRNA reads, mapped rows ending ",\n", %.15g RPM).  sample_names: S strings.
+ * mirna_reads_filtered / mirna_uniq_filtered (nullable, S entries) receive the logHash numbers of :543-544.
+ * The isomiR tables (--diff-isomirs), graphs and the HTML report stay with the Perl driver. */
+int32_t     mirge_write_tables(mirge_ctx*, const char* merges_csv, const char* output_dir, const char* const* sample_names,
+                               uint64_t* mirna_reads_filtered, uint64_t* mirna_uniq_filtered);
+
 /* ---- timing -------------------------------------------------------------- */
 /* Device time (HIP events on the library's stream) spent in the last
  * mirge_collapse_* call / the last mirge_annotate() + count-vector pass, ms. */

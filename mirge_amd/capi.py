@@ -25,7 +25,7 @@ EXPORTS = [
     "mirge_collapse_fastq", "mirge_collapse_fastq_mem", "mirge_collapse_fastq_dev", "mirge_collapse_seqs", "mirge_collapse_ascii_dev", "mirge_pack_dev",
     "mirge_collapse_packed_dev", "mirge_annotate", "mirge_round_stats", "mirge_counts", "mirge_counts_flat_len",
     "mirge_counts_flat_get", "mirge_counts_flat_set", "mirge_n_unique", "mirge_unique", "mirge_export_uniques",
-    "mirge_n_counts", "mirge_export_counts", "mirge_last_timing", "mirge_kernel_times",
+    "mirge_n_counts", "mirge_export_counts", "mirge_last_timing", "mirge_kernel_times", "mirge_write_tables",
 ]
 
 
@@ -67,6 +67,7 @@ def load():
     L.mirge_reset.argtypes = [vp, i32]
     L.mirge_load_library_fasta.argtypes = [vp, i32, C.c_char_p]
     L.mirge_load_library_ebwt.argtypes = [vp, i32, C.c_char_p]
+    L.mirge_write_tables.argtypes = [vp, C.c_char_p, C.c_char_p, vp, vp, vp]
     L.mirge_load_library_mem.argtypes = [vp, i32, i32, C.c_char_p, vp, vp]
     L.mirge_lib_size.argtypes = [vp, i32]
     L.mirge_lib_name.restype = C.c_char_p; L.mirge_lib_name.argtypes = [vp, i32, i32]
@@ -143,6 +144,16 @@ class Context:
 
     def load_library_fasta(self, lib, path):
         self._chk(self.L.mirge_load_library_fasta(self.h, lib, path.encode()))
+
+    def write_tables(self, merges_csv, output_dir, sample_names):
+        """summarize bookkeeping + miRNAmerge + filter + the four CSV tables in native code (miRge.pl:453-554, 690-907).
+        Returns (mirnaReadsFiltered[S], mirnaUniqFiltered[S])."""
+        S = len(sample_names)
+        arr = (C.c_char_p * S)(*[n.encode() for n in sample_names])
+        tot = np.zeros(S, dtype=np.uint64); uq = np.zeros(S, dtype=np.uint64)
+        self._chk(self.L.mirge_write_tables(self.h, merges_csv.encode() if merges_csv else None, output_dir.encode(), arr,
+                                            tot.ctypes.data, uq.ctypes.data))
+        return tot, uq
 
     def load_library_ebwt(self, lib, base):
         self._chk(self.L.mirge_load_library_ebwt(self.h, lib, base.encode()))

@@ -21,6 +21,7 @@
 #include <thread>
 #include <vector>
 
+#include <map>
 #include <fcntl.h>
 #include <zlib.h>
 #include <sys/stat.h>
@@ -1363,6 +1364,122 @@ int32_t mirge_unique(mirge_ctx* c, uint64_t i, const char** seq, int32_t ref_idx
         *counts = c->uniq_counts.data();
     }
     return MIRGE_OK;
+}
+
+// ---- the host tail of the run in native code: summarize's bookkeeping, miRNAmerge, filter and the four
+// tables of writeDataToCSV, for a batch mode without Perl.  Same steps, same quirks, as the reference's subs.
+int32_t mirge_write_tables(mirge_ctx* c, const char* merges_csv, const char* output_dir, const char* const* sample_names,
+                           uint64_t* mirna_reads_filtered, uint64_t* mirna_uniq_filtered) {
+    if (!c || !output_dir || !sample_names) return c ? fail(c, MIRGE_E_ARG, "null argument") : MIRGE_E_ARG;
+    if (!c->annotated || !c->counts_valid) return fail(c, MIRGE_E_ARG, "mirge_annotate has not run");
+    if (c->n_rounds != 5) return fail(c, MIRGE_E_ARG, "the tables are those of the five-round cascade (miRge.pl:111)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = fetch_host(c);
+    if (rc) return rc;
+    const int S = c->S;
+    const Lib& mir = c->libs[MIRGE_LIB_MIRNA];
+    const size_t M = mir.names.size();
+    struct Ent { std::vector<uint64_t> quant, iscan; };
+    std::map<std::string, Ent> mirHash;                        // std::map orders bytewise: the `sort keys` of miRge.pl:878, 894
+    auto entry = [&](const std::string& k) -> Ent& {
+        Ent& e = mirHash[k];
+        if (e.quant.empty()) { e.quant.assign((size_t)S, 0); e.iscan.assign((size_t)S, 0); }
+        return e;
+    };
+    // summarize, miRge.pl:457-463 (keys = what bowtie-inspect -n prints) and :473-476 (counts go to the name bowtie reports)
+    for (size_t m = 0; m < M; ++m) entry(mir.names[m]);
+    for (size_t m = 0; m < M; ++m)
+        for (int s = 0; s < S; ++s) {
+            const uint64_t q = c->h_quant[m * S + s], i = c->h_iscan[m * S + s];
+            if (q || i) { Ent& e = entry(mir.short_names[m]); e.quant[(size_t)s] += q; e.iscan[(size_t)s] += i; }
+        }
+    // miRNAmerge, miRge.pl:496-524
+    if (merges_csv) {
+        std::string data;
+        FILE* f = fopen(merges_csv, "rb");
+        if (f) {
+            fclose(f);
+            rc = read_file(c, merges_csv, data);
+            if (rc) return rc;
+            size_t i = 0;
+            while (i < data.size()) {
+                size_t e = data.find('\n', i); if (e == std::string::npos) e = data.size();
+                std::vector<std::string> cols;                  // split(',', $line): trailing empty fields dropped; chomp strips only "\n"
+                size_t a = i;
+                for (;;) { size_t b = data.find(',', a); if (b == std::string::npos || b > e) b = e; cols.emplace_back(data, a, b - a); if (b >= e) break; a = b + 1; }
+                while (!cols.empty() && cols.back().empty()) cols.pop_back();
+                for (size_t k = 1; k < cols.size(); ++k) {
+                    auto it = mirHash.find(cols[k]);
+                    if (it == mirHash.end()) continue;
+                    for (int j = 0; j < S; ++j)
+                        if (it->second.quant[(size_t)j] > 0) {                                  // :511
+                            Ent& t = entry(cols[0]);
+                            const uint64_t q = it->second.quant[(size_t)j], sc = it->second.iscan[(size_t)j];
+                            t.quant[(size_t)j] += q; t.iscan[(size_t)j] += sc;                  // :512-513
+                        }
+                    mirHash.erase(cols[k]);                                                      // :516
+                }
+                i = e + 1;
+            }
+        }                                                       // a missing merges file is not an error (:521-523)
+    }
+    // filter, miRge.pl:526-554
+    std::vector<uint64_t> tot((size_t)S, 0), uq((size_t)S, 0);
+    for (auto& kv : mirHash) for (int i = 0; i < S; ++i) if (kv.second.iscan[(size_t)i] < 2) kv.second.quant[(size_t)i] = 0;
+    for (auto& kv : mirHash) for (int i = 0; i < S; ++i) if (kv.second.quant[(size_t)i] > 0) { tot[(size_t)i] += kv.second.quant[(size_t)i]; uq[(size_t)i] += 1; }
+    for (int i = 0; i < S; ++i) { if (mirna_reads_filtered) mirna_reads_filtered[i] = tot[(size_t)i]; if (mirna_uniq_filtered) mirna_uniq_filtered[i] = uq[(size_t)i]; }
+    // writeDataToCSV, miRge.pl:690-907
+    const std::string dir = output_dir;
+    (void)mkdir(dir.c_str(), 0777);
+    std::string head = "uniqueSequence,annotFlag,exact miRNA,hairpin miRNA,non miRNA/mRNA RNA,mRNA,isomiR miRNA", names;
+    for (int i = 0; i < S; ++i) { names += ","; names += sample_names[i] ? sample_names[i] : ""; }
+    head += names + "\n";
+    FILE* fm = fopen((dir + "/mapped.csv").c_str(), "wb");
+    FILE* fu = fopen((dir + "/unmapped.csv").c_str(), "wb");
+    FILE* fc = fopen((dir + "/miR.Counts.csv").c_str(), "wb");
+    FILE* fr = fopen((dir + "/miR.RPM.csv").c_str(), "wb");
+    if (!fm || !fu || !fc || !fr) {
+        for (FILE* f : {fm, fu, fc, fr}) if (f) fclose(f);
+        return fail(c, MIRGE_E_IO, "cannot write the tables into " + dir);
+    }
+    fputs(head.c_str(), fm); fputs(head.c_str(), fu);
+    const uint64_t U0 = c->cls[0].U, U = U0 + c->cls[1].U;
+    std::vector<uint64_t> cnt((size_t)S);
+    std::string row;
+    for (uint64_t u = 0; u < U; ++u) {
+        const int k = u < U0 ? 0 : 1; const uint64_t j = k ? u - U0 : u; const int KW = k ? 6 : 2;
+        char buf[128]; int len = 0;
+        decode_key(&c->h_keys[k][(size_t)j * KW], KW, buf, &len);
+        const int r = c->h_round[k][(size_t)j];
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (uint64_t e = c->csr_off[(size_t)u]; e < c->csr_off[(size_t)u + 1]; ++e) cnt[c->csr_sample[(size_t)e]] += c->csr_count[(size_t)e];
+        row.assign(buf, (size_t)len);
+        row += r > 0 ? ",1" : ",0";
+        for (int q = 1; q <= 5; ++q) { row += ","; if (q == r) row += c->libs[c->rounds[q - 1].lib].short_names[(size_t)c->h_ref[k][(size_t)j]]; }
+        for (int i = 0; i < S; ++i) { row += ","; row += std::to_string(cnt[(size_t)i]); }
+        row += r > 0 ? ",\n" : "\n";                            // mapped rows end ",\n" (:748-749), unmapped rows do not (:853-860)
+        fputs(row.c_str(), r > 0 ? fm : fu);
+    }
+    std::string h2 = "miRNA" + names + "\n";
+    fputs(h2.c_str(), fc); fputs(h2.c_str(), fr);
+    row = "miRNAtotal";
+    for (int i = 0; i < S; ++i) { row += ","; if (uq[(size_t)i]) row += std::to_string(tot[(size_t)i]); }      // undef => empty cell (:874)
+    row += "\n"; fputs(row.c_str(), fc);
+    for (auto& kv : mirHash) {
+        row = kv.first;
+        for (int i = 0; i < S; ++i) { row += ","; row += std::to_string(kv.second.quant[(size_t)i]); }
+        row += "\n"; fputs(row.c_str(), fc);
+        row = kv.first;
+        for (int i = 0; i < S; ++i) {
+            char num[64] = "0";
+            if (tot[(size_t)i]) snprintf(num, sizeof num, "%.15g", (double)(1000000ull * kv.second.quant[(size_t)i]) / (double)tot[(size_t)i]);   // :897-898
+            row += ","; row += num;
+        }
+        row += "\n"; fputs(row.c_str(), fr);
+    }
+    bool bad = false;
+    for (FILE* f : {fm, fu, fc, fr}) bad |= fclose(f) != 0;
+    return bad ? fail(c, MIRGE_E_IO, "short write in " + dir) : MIRGE_OK;
 }
 
 uint64_t mirge_n_counts(const mirge_ctx* c) { return c ? c->cls[0].coo_n + c->cls[1].coo_n : 0; }

@@ -295,3 +295,25 @@ def test_golden_tables_from_ebwt_only_species_dir(tmp_path, name):
     run.run(out)
     util.check_run_against_golden(run, case, out)
     run.ctx.close()
+
+
+@pytest.mark.parametrize("name", util.golden_cases())
+def test_native_tables_equal_reference(tmp_path, name):
+    """mirge_write_tables (summarize bookkeeping + miRNAmerge + filter + writeDataToCSV in native code) against the
+    tables the unmodified reference wrote: Counts/RPM byte-identical, mapped/unmapped as row sets."""
+    import os
+    case = util.golden_case(name)
+    S = len(case["fastqs"])
+    with capi.Context(case["species"], S, 0) as ctx:
+        for i, f in enumerate(case["fastqs"]):
+            ctx.collapse_fastq(f, i)
+        ctx.annotate()
+        out = str(tmp_path / "out")
+        tot, uq = ctx.write_tables(os.path.join(case["species"], "merges.csv"), out, case["names"])
+    exp = case["expected"]
+    for f in ("miR.Counts.csv", "miR.RPM.csv"):
+        assert open(os.path.join(out, f)).read() == open(os.path.join(exp, f)).read(), f
+    for f in ("mapped.csv", "unmapped.csv"):
+        assert util.rows(os.path.join(out, f)) == util.rows(os.path.join(exp, f)), f
+    tline = open(os.path.join(exp, "miR.Counts.csv")).read().split("\n")[1].split(",")[1:]
+    assert [str(int(t)) if u else "" for t, u in zip(tot, uq)] == tline

@@ -86,3 +86,25 @@ def test_perl_binding_on_golden(name):
         annot = [names[lib_of_round[r]][refs[r]] if refs[r] >= 0 else "" for r in range(5)]
         assert exp[seq] == (annot, counts), seq
     assert n_uniq == len(exp)
+
+
+@pytest.mark.parametrize("name", util.golden_cases())
+def test_batch_cli_writes_the_reference_tables(tmp_path, name):
+    """tools/mirge-annotate (batch mode without Perl): tables equal to the unmodified reference's, stats lines equal to
+    its logHash numbers."""
+    import re
+    case = util.golden_case(name)
+    out = str(tmp_path / "out")
+    r = subprocess.run([os.path.join(ROOT, "tools", "mirge-annotate"), "--species", case["species"], "--SampleFiles", ",".join(case["fastqs"]),
+                        "--SampleNames=" + ",".join(case["names"]), "--outputDir", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exp = case["expected"]
+    for f in ("miR.Counts.csv", "miR.RPM.csv"):
+        assert open(os.path.join(out, f)).read() == open(os.path.join(exp, f)).read(), f
+    for f in ("mapped.csv", "unmapped.csv"):
+        assert util.rows(os.path.join(out, f)) == util.rows(os.path.join(exp, f)), f
+    aligned = [int(x) for x in re.findall(r"readsAligned (\d+)", r.stdout)]
+    assert aligned == [case["stats"]["annotStats"][k]["readsAligned"] for k in range(5)]
+    bad = subprocess.run([os.path.join(ROOT, "tools", "mirge-annotate"), "--species", str(tmp_path / "nowhere"), "--SampleFiles", case["fastqs"][0]],
+                         capture_output=True, text=True)
+    assert bad.returncode == 1 and "cannot find" in bad.stderr

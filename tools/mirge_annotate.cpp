@@ -1,0 +1,59 @@
+// mirge-annotate -- batch mode without Perl over libmirge_hip.so: what miRge.pl:133-150 does between the
+// command line and the tables, minus graphs / HTML / isomiR tables:
+//   per sample  trimRaw + `cutadapt -u` + quantReads (miRge.pl:259-262)   -> mirge_collapse_raw_fastq   (--adapter given)
+//               or quantReads on an already trimmed file (:291-319)        -> mirge_collapse_fastq
+//   runAnnotationPipeline (:321-372) + summarize (:453-494)               -> mirge_annotate
+//   miRNAmerge, filter, writeDataToCSV (:496-554, 690-907)                -> mirge_write_tables
+// Option names follow miRge.pl:59 where they exist (--species is a directory here: miRge.seqLibs/<species>).
+//   mirge-annotate --species DIR --SampleFiles a.fastq,b.fastq.gz [--SampleNames a,b] [--adapter illumina|ion|none|+N|SEQ]
+//                  [--trim5 N] [--trim3 N] [--outputDir DIR] [--device N]
+#include "../include/mirge_hip.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static std::vector<std::string> split(const std::string& s) {
+    std::vector<std::string> v; size_t a = 0;
+    for (;;) { size_t b = s.find(',', a); v.emplace_back(s, a, b == std::string::npos ? std::string::npos : b - a); if (b == std::string::npos) break; a = b + 1; }
+    return v;
+}
+
+int main(int argc, char** argv) {
+    std::string species, files, names, adapter, out = "miRge.out"; int trim5 = 0, trim3 = 0, device = 0; bool raw = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i], v; size_t eq = a.find('=');
+        if (eq != std::string::npos) { v = a.substr(eq + 1); a = a.substr(0, eq); } else if (i + 1 < argc) v = argv[++i];
+        while (a.size() > 1 && a[0] == '-') a.erase(0, 1);
+        if (a == "species") species = v; else if (a == "SampleFiles") files = v; else if (a == "SampleNames") names = v;
+        else if (a == "adapter") { adapter = v; raw = true; } else if (a == "trim5") trim5 = atoi(v.c_str()); else if (a == "trim3") trim3 = atoi(v.c_str());
+        else if (a == "outputDir") out = v; else if (a == "device") device = atoi(v.c_str());
+        else { fprintf(stderr, "mirge-annotate: unknown option --%s\n", a.c_str()); return 2; }
+    }
+    if (species.empty() || files.empty()) { fprintf(stderr, "usage: mirge-annotate --species DIR --SampleFiles a.fastq,b.fastq [--SampleNames a,b] [--adapter X] [--trim5 N] [--trim3 N] [--outputDir DIR]\n"); return 2; }
+    std::vector<std::string> F = split(files), N = names.empty() ? F : split(names);
+    if (N.size() != F.size()) { fprintf(stderr, "mirge-annotate: %zu sample names for %zu sample files\n", N.size(), F.size()); return 2; }
+    mirge_ctx* c = mirge_open(species.c_str(), (int32_t)F.size(), device);
+    if (!c) { fprintf(stderr, "mirge-annotate: %s\n", mirge_last_error(nullptr)); return 1; }
+    auto die = [&](const std::string& what) { fprintf(stderr, "mirge-annotate: %s: %s\n", what.c_str(), mirge_last_error(c)); mirge_close(c); return 1; };
+    for (size_t i = 0; i < F.size(); ++i) {
+        uint64_t total = 0, kept = 0; int32_t phred = 33;
+        if (raw) { if (mirge_collapse_raw_fastq(c, F[i].c_str(), (int32_t)i, adapter.c_str(), trim5, trim3, &total, &kept, &phred)) return die(F[i]); }
+        else { if (mirge_collapse_fastq(c, F[i].c_str(), (int32_t)i, &kept)) return die(F[i]); total = kept; }
+        printf("%s: totalReads %llu trimmedReads %llu\n", N[i].c_str(), (unsigned long long)total, (unsigned long long)kept);
+    }
+    if (mirge_annotate(c)) return die("annotation");
+    static const char* rn[5] = {"exact miRNA", "hairpin miRNA", "non miRNA/mRNA RNA", "mRNA", "isomiR miRNA"};      // miRge.pl:111
+    for (int r = 1; r <= 5; ++r) {
+        uint64_t p = 0, a = 0; double sec = 0;
+        if (mirge_round_stats(c, r, &p, &a, &sec)) return die("round statistics");
+        printf("%s: readsProcessed %llu readsAligned %llu cpuTime %.6f\n", rn[r - 1], (unsigned long long)p, (unsigned long long)a, sec);
+    }
+    std::vector<const char*> np; for (auto& s : N) np.push_back(s.c_str());
+    std::vector<uint64_t> tot(F.size()), uq(F.size());
+    if (mirge_write_tables(c, (species + "/merges.csv").c_str(), out.c_str(), np.data(), tot.data(), uq.data())) return die("tables");
+    for (size_t i = 0; i < F.size(); ++i) printf("%s: mirnaReadsFiltered %llu mirnaUniqFiltered %llu\n", N[i].c_str(), (unsigned long long)tot[i], (unsigned long long)uq[i]);
+    mirge_close(c);
+    return 0;
+}
