@@ -45,11 +45,21 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box only: MIRGE_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and swaps RCCL (which refuses two
+    # ranks on one device) for gloo, so the N > 1 code path can be run where there is a single card
+    rehearsal = os.environ.get("MIRGE_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local = 0
+        if args.merge_uniques:
+            sys.exit("MIRGE_BENCH_ONE_DEVICE rehearses the all-reduce path only: gloo has no all-to-all over device buffers")
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     prof = getattr(synth.Profile, args.profile)()
     mix = synth.Mixture.default() if args.mixture == "default" else synth.Mixture.isomir_rich()
