@@ -973,30 +973,36 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
 // count vectors (miRge.pl:465-493) over one sample's (unique id, count) entries.
 // Per-block partial sums live in LDS (category totals, length histogram, and -- when the
 // miRNA library is small enough -- the whole quant/iscan column), then one flush of atomics.
-constexpr int CNT_LDS_M = 6144;
+constexpr int CNT_LDS_M = 3584;        // 2 x 3584 x 8 B = 56 KB of dynamic LDS (below the 64 KB a launch may ask for without a function attribute)
+// dynamic LDS: 2 * M words when M <= CNT_LDS_M (the quant and iscan columns), else none -- a human-sized miRNA library
+// (2.7 k names) takes 43 KB and three blocks fit a CU, where a fixed 6144-name array held one
 template <int KW>
 __global__ void __launch_bounds__(256)
 k_counts(const uint32_t* __restrict__ coo_g, const uint32_t* __restrict__ coo_c, uint32_t n, int sample, int S,
          const uint64_t* __restrict__ ukeys, const uint8_t* __restrict__ ann_round, const int32_t* __restrict__ ann_ref,
          int M, int round_mirna_a, int round_mirna_b, unsigned long long* quant, unsigned long long* iscan,
          unsigned long long* cat, unsigned long long* lenhist, unsigned long long* tuniq) {
+    extern __shared__ unsigned long long s_dyn[];
     __shared__ unsigned long long s_cat[5];
     __shared__ unsigned long long s_len[128];
     __shared__ unsigned long long s_tu;
-    __shared__ unsigned long long s_q[CNT_LDS_M];
-    __shared__ unsigned long long s_i[CNT_LDS_M];
     const bool ldsm = M <= CNT_LDS_M;
+    unsigned long long* s_q = s_dyn;
+    unsigned long long* s_i = s_dyn + (ldsm ? M : 0);
     for (int j = threadIdx.x; j < 128; j += blockDim.x) s_len[j] = 0;
     if (threadIdx.x < 5) s_cat[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_tu = 0;
     if (ldsm) for (int j = threadIdx.x; j < M; j += blockDim.x) { s_q[j] = 0; s_i[j] = 0; }
     __syncthreads();
+    // the five category totals and the entry count are kept per thread and folded once: as LDS atomics every lane of
+    // every wave hit the same six words
+    unsigned long long c_cat[5] = {0, 0, 0, 0, 0}, c_tu = 0;
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
         uint32_t g = coo_g[e];
         unsigned long long c = coo_c[e];
         int len = key_len<KW>(&ukeys[(uint64_t)g * KW]);
         int r = ann_round[g];
-        atomicAdd(&s_tu, 1ull);                                      // miRge.pl:468
+        c_tu += 1;                                                   // miRge.pl:468
         atomicAdd(&s_len[len & 127], c);                             // miRge.pl:315
         int catidx;
         if (r == round_mirna_a || r == round_mirna_b) {              // miRge.pl:469
@@ -1009,7 +1015,19 @@ k_counts(const uint32_t* __restrict__ coo_g, const uint32_t* __restrict__ coo_c,
             }
         } else if (r == 0) catidx = 4;                               // miRge.pl:489 remReads
         else catidx = (r >= 2 && r <= 4) ? r - 1 : 4;                // :480 hairpin, :483 other, :486 mRNA
-        atomicAdd(&s_cat[catidx], c);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) c_cat[q] += (q == catidx) ? c : 0ull;
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        unsigned long long v = c_cat[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_cat[q], v);
+    }
+    {
+        unsigned long long v = c_tu;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_tu, v);
     }
     __syncthreads();
     for (int j = threadIdx.x; j < 128; j += blockDim.x) if (s_len[j]) atomicAdd(&lenhist[(uint64_t)j * S + sample], s_len[j]);

@@ -850,8 +850,10 @@ template <int KW>
 int counts_class(mirge_ctx* c, Class& C, int M) {
     for (auto& sg : C.segs) {
         if (!sg.count) continue;
-        uint32_t grid = (uint32_t)std::min<uint64_t>(512, (sg.count + 255) / 256);
-        hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(256), 0, C.st, C.coo_g.as<uint32_t>() + sg.start,
+        const size_t lds = M <= CNT_LDS_M ? (size_t)2 * M * 8 : 0;
+        const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (150u << 10) / (lds + 2048)));      // blocks a CU's LDS holds
+        uint32_t grid = (uint32_t)std::min<uint64_t>(256 * per_cu, (sg.count + 255) / 256);
+        hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(256), lds, C.st, C.coo_g.as<uint32_t>() + sg.start,
                            C.coo_c.as<uint32_t>() + sg.start, (uint32_t)sg.count, sg.sample, c->S, C.ukeys.as<uint64_t>(),
                            C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), M, 1, 5,
                            c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu);

@@ -317,3 +317,14 @@ def test_native_tables_equal_reference(tmp_path, name):
         assert util.rows(os.path.join(out, f)) == util.rows(os.path.join(exp, f)), f
     tline = open(os.path.join(exp, "miR.Counts.csv")).read().split("\n")[1].split(",")[1:]
     assert [str(int(t)) if u else "" for t, u in zip(tot, uq)] == tline
+
+
+def test_large_mirna_library_counts_through_global_atomics(oracle):
+    """More miRNA names than the count kernel keeps in LDS (CNT_LDS_M = 3584): quant / iscan then go straight to
+    global atomics."""
+    prof = synth.Profile(n_mirna=4200, n_snp=10, n_family=6, n_hairpin=300, n_other=400, other_median=150.0,
+                         n_mrna=200, mrna_median=1500.0, mrna_cap=8000)
+    libs, _ = synth.make_libraries(prof, 909)
+    assert libs["mirna"].n > 3584
+    samples = [synth.make_reads(libs, 60000, 910 + s) for s in range(2)]
+    _compare_with_oracle(oracle, libs, samples)
