@@ -96,6 +96,8 @@ def main():
         if w:
             k48_parts.append(t48[:w].clone())
         torch.cuda.synchronize()
+        if rank == 0 and c % 20 == 19:
+            print("[bench] %d / %d reads generated and packed" % (b + m, N), file=sys.stderr, flush=True)
     k48 = torch.cat(k48_parts) if k48_parts else torch.empty((1, 6), dtype=torch.int64, device="cuda")
     n48 = N - n16
     del t16, t48, k48_parts

@@ -111,6 +111,7 @@ struct mirge_ctx {
     int S = 1;
     hipStream_t st = nullptr, st2 = nullptr;        // st: everything; st2: the 48-byte key class inside collapse_packed / annotate
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};   // timing marks of the last collapse / cascade call (made once: no per-call create, no leak on an error return)
     std::string err;
     Lib libs[MIRGE_N_LIBS];
     int n_rounds = 5;
@@ -405,8 +406,7 @@ int collapse_packed(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48
     if (sample < 0 || sample >= c->S) return fail(c, MIRGE_E_ARG, "sample index out of range");
     c->annotated = false; c->counts_valid = false; c->host_valid = false;
     kt_clear(c, "collapse");
-    hipEvent_t a, b;
-    HIPCHK(c, hipEventCreate(&a)); HIPCHK(c, hipEventCreate(&b));
+    hipEvent_t a = c->ev_t[0], b = c->ev_t[1];
     HIPCHK(c, hipEventRecord(a, c->st));
     int rc = collapse_both(c, (const uint64_t*)d16, n16, nullptr, (const uint64_t*)d48, n48, nullptr, sample);
     if (!rc) {
@@ -415,7 +415,6 @@ int collapse_packed(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48
         float ms = 0; (void)hipEventElapsedTime(&ms, a, b); c->collapse_ms = ms;
         kt_resolve(c);
     }
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     return rc;
 }
 
@@ -900,8 +899,7 @@ int annotate(mirge_ctx* c) {
     c->d_len = c->d_cat + w_cat; c->d_tu = c->d_len + w_len;
     c->cls[0].act_n = c->d_tu + w_tu; c->cls[1].act_n = c->cls[0].act_n + (MIRGE_MAX_ROUNDS + 1);
     HIPCHK(c, hipMemsetAsync(c->state.p, 0, w_all * 8, c->st));
-    hipEvent_t e0, e1, e2;
-    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
+    hipEvent_t e0 = c->ev_t[0], e1 = c->ev_t[1], e2 = c->ev_t[2];
     HIPCHK(c, hipEventRecord(e0, c->st));
     // the 48-byte class (reads with N or longer than 56 nt: a fraction of a percent) runs its cascade on st2 beside
     // the 16-byte class; the two meet only in atomically updated counters.  Kernel times are those of the 16-byte class.
@@ -931,7 +929,6 @@ int annotate(mirge_ctx* c) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1); c->annotate_ms = ms;
     (void)hipEventElapsedTime(&ms, e1, e2); c->counts_ms = ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     kt_resolve(c);
     uint64_t hs[MIRGE_MAX_ROUNDS * 2] = {};
     for (int r = 0; r < c->n_rounds; ++r)
@@ -1033,8 +1030,9 @@ mirge_ctx* mirge_open(const char* species_dir, int32_t n_samples, int32_t device
     if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->st2) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&c->ev_t[0]) != hipSuccess || hipEventCreate(&c->ev_t[1]) != hipSuccess || hipEventCreate(&c->ev_t[2]) != hipSuccess ||
         hipHostMalloc((void**)&c->h_ctr, 128 + 64) != hipSuccess) {
-        fail(nullptr, MIRGE_E_HIP, "cannot create stream / pinned buffer"); delete c; return nullptr;
+        fail(nullptr, MIRGE_E_HIP, "cannot create stream / events / pinned buffer"); mirge_close(c); return nullptr;
     }
     c->cls[0].st = c->st; c->cls[1].st = c->st2;
     c->cls[0].h_ctr = c->h_ctr + 16; c->cls[1].h_ctr = c->h_ctr + 20;      // inside the pinned block
@@ -1084,6 +1082,7 @@ void mirge_close(mirge_ctx* c) {
     for (auto& k : c->kt) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_state) (void)hipHostFree(c->h_state);
+    for (auto& e : c->ev_t) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->st2) (void)hipStreamDestroy(c->st2);
