@@ -278,14 +278,18 @@ class Context:
     def n_unique(self):
         return self.L.mirge_n_unique(self.h)
 
-    def export_uniques(self):
+    def export_uniques(self, with_seqs=True):
+        """(seqs[U][128] zero padded, lens, ann_round, ann_ref, ann_amb); with_seqs=False leaves the sequences out
+        (seqs and lens come back as None): the annotation arrays of a 50M-unique table without 7 GB of text."""
         U = self.n_unique()
         stride = 128
-        seqs = np.zeros((max(U, 1), stride), dtype=np.uint8)
-        lens = np.zeros(max(U, 1), dtype=np.uint8)
+        seqs = np.zeros((max(U, 1), stride), dtype=np.uint8) if with_seqs else None
+        lens = np.zeros(max(U, 1), dtype=np.uint8) if with_seqs else None
         rnd = np.zeros(max(U, 1), dtype=np.int8); ref = np.zeros(max(U, 1), dtype=np.int32); amb = np.zeros(max(U, 1), dtype=np.uint8)
-        self._chk(self.L.mirge_export_uniques(self.h, seqs.ctypes.data, stride, lens.ctypes.data, rnd.ctypes.data,
-                                              ref.ctypes.data, amb.ctypes.data))
+        self._chk(self.L.mirge_export_uniques(self.h, seqs.ctypes.data if with_seqs else None, stride,
+                                              lens.ctypes.data if with_seqs else None, rnd.ctypes.data, ref.ctypes.data, amb.ctypes.data))
+        if not with_seqs:
+            return None, None, rnd[:U], ref[:U], amb[:U]
         return seqs[:U], lens[:U], rnd[:U], ref[:U], amb[:U]
 
     def export_counts(self):

@@ -151,7 +151,7 @@ k_collapse_local(const uint64_t* __restrict__ keys, const uint32_t* __restrict__
 #pragma unroll
             for (int w = 0; w < KW; ++w) k[w] = tk[idx * KW + w];
             uint32_t gi = base + idx;
-            uint32_t h = (key_hash<KW>(k) >> 7) & lmask;       // different bits than the tile table used
+            uint32_t h = slot_hash<KW>(k) & lmask;             // different bits than the tile table used
             uint32_t g;
             bool claimed = false;
             for (;;) {
@@ -217,7 +217,7 @@ k_collapse_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ 
             uint64_t k[KW];
 #pragma unroll
             for (int w = 0; w < KW; ++w) k[w] = keys[(uint64_t)i * KW + w];
-            uint32_t h = (key_hash<KW>(k) >> 7) & gmask;
+            uint32_t h = slot_hash<KW>(k) & gmask;
             for (;;) {
                 uint32_t o = gslots[h];
                 if (o == EMPTY) break;
@@ -277,7 +277,7 @@ k_gtable_insert(const uint64_t* __restrict__ ukeys, uint32_t g0, uint32_t g1, ui
     uint64_t k[KW];
 #pragma unroll
     for (int w = 0; w < KW; ++w) k[w] = ukeys[(uint64_t)g * KW + w];
-    uint32_t h = (key_hash<KW>(k) >> 7) & gmask;
+    uint32_t h = slot_hash<KW>(k) & gmask;
     for (;;) {
         if (atomicCAS(&gslots[h], EMPTY, g) == EMPTY) break;
         h = (h + 1) & gmask;

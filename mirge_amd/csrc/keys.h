@@ -31,6 +31,18 @@ template <int KW> MG_HD uint32_t key_hash(const uint64_t* k) {
     for (int i = 0; i < KW; ++i) { h ^= k[i]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
     return (uint32_t)h;
 }
+// All 64 bits of the same mix (key_hash is its low half).  The collapse tables take their slot from bits 16..47
+// (slot_hash): the 25 bits that `key_hash >> 7` leaves gave at most 2^25 distinct starting slots, so a table of more
+// than 33M uniques (a 100M-read shard) degenerated into probe chains millions of slots long.  The shard owner
+// (shard.h) takes bits 41..63, independent of both.
+template <int KW> MG_HD uint64_t key_hash64(const uint64_t* k) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int i = 0; i < KW; ++i) { h ^= k[i]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
+    return h;
+}
+MG_HD uint32_t slot_of_hash(uint64_t h64) { return (uint32_t)(h64 >> 16); }
+template <int KW> MG_HD uint32_t slot_hash(const uint64_t* k) { return slot_of_hash(key_hash64<KW>(k)); }
 template <int KW> MG_HD bool key_eq(const uint64_t* a, const uint64_t* b) {
     bool e = true;
 #pragma unroll

@@ -322,6 +322,10 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
     if (n == 0) return MIRGE_OK;
     hipStream_t st = C.st;
     uint64_t capL = pow2_at_least((uint64_t)n + n / 4);      // load <= 0.8 even if every read is distinct; smaller table = more of it cache-resident
+    if (capL > (1ull << 32)) {                               // slots are addressed by 32 hash bits
+        if ((uint64_t)n > 3ull << 30) return fail(c, MIRGE_E_LIMIT, "more than 3 * 2^30 reads in one collapse call");
+        capL = 1ull << 32;
+    }
     HIPCHK(c, C.ws_lslots.ensure(capL * 4, false, 0, st));
     HIPCHK(c, C.ws_cnt.ensure((size_t)n * 4, false, 0, st));
     HIPCHK(c, C.ws_cnt0.ensure((size_t)n * 4, false, 0, st));
@@ -332,6 +336,10 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
     bool use_g = C.U > 0;
     if (use_g) {
         uint64_t need = pow2_at_least(2ull * (C.U + n));
+        if (need > (1ull << 32)) {
+            if (C.U + n > 3ull << 30) return fail(c, MIRGE_E_LIMIT, "more than 3 * 2^30 unique sequences");
+            need = 1ull << 32;
+        }
         if (!C.gvalid || C.gcap < need) {
             HIPCHK(c, C.gslots.ensure(need * 4, false, 0, st));
             C.gcap = need;
@@ -1330,7 +1338,7 @@ int32_t mirge_export_uniques(mirge_ctx* c, char* seqs, uint32_t stride, uint8_t*
         int KW = k == 0 ? 2 : 6;
         for (uint64_t i = 0; i < c->cls[k].U; ++i, ++u) {
             char buf[128]; int len = 0;
-            decode_key(&c->h_keys[k][(size_t)i * KW], KW, buf, &len);
+            if (seqs || lens) decode_key(&c->h_keys[k][(size_t)i * KW], KW, buf, &len);
             if (seqs) {
                 if ((uint32_t)len > stride) return fail(c, MIRGE_E_ARG, "stride smaller than a unique sequence");
                 memset(seqs + u * stride, 0, stride); memcpy(seqs + u * stride, buf, (size_t)len);

@@ -7,7 +7,8 @@
 // Record formats (what travels through the all-to-all):
 //   16-byte class: 24 B = key[2] | sample u32 | count u32
 //   48-byte class: 56 B = key[6] | sample u32 | count u32
-// owner(key, world) = floor((key_hash(key) >> 9) * world / 2^23).
+// owner(key, world) = floor((key_hash64(key) >> 41) * world / 2^23): the top 23 bits, which the collapse tables do
+// not use, so the keys a rank owns still spread over its whole table.
 #pragma once
 #include "keys.h"
 
@@ -16,7 +17,7 @@ namespace mg {
 constexpr int SHARD_MAX_WORLD = 64;
 
 template <int KW> MG_HD uint32_t key_owner(const uint64_t* k, uint32_t world) {
-    return (uint32_t)((((uint64_t)key_hash<KW>(k) >> 9) * world) >> 23);        // key_hash is 32 bits: (h >> 9) in [0, 2^23)
+    return (uint32_t)(((key_hash64<KW>(k) >> 41) * world) >> 23);
 }
 
 #ifdef __HIPCC__

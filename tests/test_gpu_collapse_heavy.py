@@ -34,3 +34,24 @@ def test_heavy_hitters_and_two_samples():
         ctx.collapse_seqs(seqs[250000:], 1, lens[250000:])
         got = _table(ctx)
     assert got == {k: (want[0].get(k, 0), want[1].get(k, 0)) for k in set(want[0]) | set(want[1])}
+
+
+@pytest.mark.timeout(120)
+def test_more_uniques_than_a_25_bit_hash_can_spread():
+    """45M reads, ~39M distinct: the claim table takes its slot from 32 hash bits.  (With the 25 bits of `key_hash >> 7`
+    a table of more than 2^25 uniques degenerated into probe chains millions of slots long: a 100M-read shard hung.)"""
+    import torch
+    N = 45_000_000
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    idx = torch.randint(0, 150_000_000, (N,), device="cuda", generator=g, dtype=torch.int64)
+    k0 = (idx * 0x9E3779B97F4A7C15) & ((1 << 40) - 1)                 # 20 nt per pool member (odd multiplier: a bijection mod 2^40)
+    k16 = torch.stack([k0, torch.full_like(k0, 20 << 56)], dim=1).contiguous()
+    k48 = torch.zeros((1, 6), dtype=torch.int64, device="cuda")
+    want = int(torch.unique(idx).numel())
+    assert want > (1 << 25)
+    torch.cuda.synchronize()
+    with capi.Context(None, 1, 0) as ctx:
+        ctx.collapse_packed_dev(k16.data_ptr(), N, k48.data_ptr(), 0, 0)
+        assert ctx.n_unique() == want
+        uid, smp, cnt = ctx.export_counts()
+        assert len(cnt) == want and int(cnt.sum()) == N
