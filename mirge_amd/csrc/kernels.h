@@ -191,10 +191,10 @@ k_collapse_local(const uint64_t* __restrict__ keys, const uint32_t* __restrict__
 // collapse, step B: every representative read (cnt > 0) becomes one (unique id, count) entry of
 // this sample.  If a table of earlier samples' uniques exists (gslots != null) it is looked up
 // first (read-only here); unseen keys are appended to ukeys at U0 + atomic rank.
-// ctr: [0] = new uniques appended, [1] = entries emitted.  gid_of (nullable): unique id per
+// ctr[0] = (new uniques appended << 32) | entries emitted.  gid_of (nullable): unique id per
 // representative read index.
 // A single hot counter takes ~12 ns per atomic on this chip, so ranks are formed per 2048-element tile
-// (block scan in LDS) and each tile costs one atomic per counter.
+// (block scan in LDS) and each tile costs one atomic.
 constexpr int EMIT_PER = 8;
 template <int KW>
 __global__ void __launch_bounds__(256)
@@ -244,8 +244,10 @@ k_collapse_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ 
     uint32_t incl = s_scan[tid];
     if (tid == 255) {
         uint32_t trep = incl & 0xFFFF, tnew = incl >> 16;
-        s_base[0] = trep ? (uint32_t)atomicAdd(&ctr[1], (unsigned long long)trep) : 0u;
-        s_base[1] = tnew ? (uint32_t)atomicAdd(&ctr[0], (unsigned long long)tnew) : 0u;
+        // both counters in ONE word (new uniques << 32 | entries; each stays below 2^32): one hot atomic per tile, not two
+        const unsigned long long old = (trep | tnew) ? atomicAdd(&ctr[0], ((unsigned long long)tnew << 32) | trep) : 0ull;
+        s_base[0] = (uint32_t)old;
+        s_base[1] = (uint32_t)(old >> 32);
     }
     __syncthreads();
     uint32_t prep = s_base[0] + (incl & 0xFFFF) - nrep;

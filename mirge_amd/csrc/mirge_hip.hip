@@ -381,7 +381,7 @@ int collapse_finish(mirge_ctx* c, Class& C, const char* tagB) {
     C.pending = false;
     if (C.pend_n == 0) { C.segs.push_back({C.pend_sample, C.coo_n, 0}); return MIRGE_OK; }
     HIPCHK(c, hipStreamSynchronize(C.st));
-    uint64_t n_new = C.h_ctr[0], n_emit = C.h_ctr[1];
+    uint64_t n_new = C.h_ctr[0] >> 32, n_emit = C.h_ctr[0] & 0xFFFFFFFFull;       // k_collapse_emit packs both into one word
     ktime(c, tagB).bytes = n_new * (KW * 8 + 4) + n_emit * 4;
     if (C.gvalid && n_new) {
         hipLaunchKernelGGL((k_gtable_insert<KW>), dim3((uint32_t)((n_new + 255) / 256)), dim3(256), 0, C.st,
