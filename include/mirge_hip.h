@@ -143,7 +143,10 @@ int32_t     mirge_round_stats(const mirge_ctx*, int32_t round, uint64_t* process
  * quant, iscan: M x S row-major (M = mirge_lib_size(MIRGE_LIB_MIRNA), row =
  * reference index); category: 5 x S (mirnaReads, hairpinReads, ornaReads,
  * mrnaReads, remReads); len_hist: (MIRGE_MAX_READ_LEN+1) x S (readLengthHash,
- * miRge.pl:315); trimmed_uniq: S (miRge.pl:468).  Any pointer may be NULL. */
+ * miRge.pl:315); trimmed_uniq: S (miRge.pl:468).  Any pointer may be NULL.
+ * With a cascade installed through mirge_set_rounds the same rule is applied by library: a read counts towards the
+ * category of the library its annotating round ran against, only rounds against the miRNA library add to quant, and
+ * only round 1 (if it is one of them) to iscan -- which is miRge.pl:469-489 for the reference's own five rounds. */
 int32_t     mirge_counts(mirge_ctx*, const uint64_t** quant, const uint64_t** iscan, const uint64_t** category,
                          const uint64_t** len_hist, const uint64_t** trimmed_uniq);
 /* Multi-GPU: the count vectors of this context as one flat uint64 buffer

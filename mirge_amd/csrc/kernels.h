@@ -982,7 +982,7 @@ template <int KW>
 __global__ void __launch_bounds__(256)
 k_counts(const uint32_t* __restrict__ coo_g, const uint32_t* __restrict__ coo_c, uint32_t n, int sample, int S,
          const uint64_t* __restrict__ ukeys, const uint8_t* __restrict__ ann_round, const int32_t* __restrict__ ann_ref,
-         int M, int round_mirna_a, int round_mirna_b, unsigned long long* quant, unsigned long long* iscan,
+         int M, uint32_t round_libs, uint32_t iscan_rounds, unsigned long long* quant, unsigned long long* iscan,
          unsigned long long* cat, unsigned long long* lenhist, unsigned long long* tuniq) {
     extern __shared__ unsigned long long s_dyn[];
     __shared__ unsigned long long s_cat[5];
@@ -1006,17 +1006,23 @@ k_counts(const uint32_t* __restrict__ coo_g, const uint32_t* __restrict__ coo_c,
         int r = ann_round[g];
         c_tu += 1;                                                   // miRge.pl:468
         atomicAdd(&s_len[len & 127], c);                             // miRge.pl:315
-        int catidx;
-        if (r == round_mirna_a || r == round_mirna_b) {              // miRge.pl:469
-            catidx = 0;
-            int32_t m = ann_ref[g];
-            if (ldsm) { atomicAdd(&s_q[m], c); if (r == round_mirna_a) atomicAdd(&s_i[m], c); }
-            else {
-                atomicAdd(&quant[(uint64_t)m * S + sample], c);      // miRge.pl:473 / 476
-                if (r == round_mirna_a) atomicAdd(&iscan[(uint64_t)m * S + sample], c);   // miRge.pl:474
+        // round_libs: 2 bits per round = the library it ran against; the read's category is that library's (for the
+        // reference cascade: rounds 1 and 5 -> miRNA, 2 -> hairpin, 3 -> other, 4 -> mRNA), and only a round against the
+        // miRNA library indexes quant / iscan -- whatever cascade mirge_set_rounds installed
+        int catidx = 4;                                              // miRge.pl:489 remReads
+        if (r > 0) {
+            const int lib = (int)((round_libs >> (2 * (r - 1))) & 3u);
+            catidx = lib;                                            // :469 miRNA, :480 hairpin, :483 other, :486 mRNA
+            if (lib == 0) {
+                const int32_t m = ann_ref[g];
+                const bool isc = (iscan_rounds >> (r - 1)) & 1u;     // miRge.pl:474: exact-miRNA round only
+                if (ldsm) { atomicAdd(&s_q[m], c); if (isc) atomicAdd(&s_i[m], c); }
+                else {
+                    atomicAdd(&quant[(uint64_t)m * S + sample], c);  // miRge.pl:473 / 476
+                    if (isc) atomicAdd(&iscan[(uint64_t)m * S + sample], c);
+                }
             }
-        } else if (r == 0) catidx = 4;                               // miRge.pl:489 remReads
-        else catidx = (r >= 2 && r <= 4) ? r - 1 : 4;                // :480 hairpin, :483 other, :486 mRNA
+        }
 #pragma unroll
         for (int q = 0; q < 5; ++q) c_cat[q] += (q == catidx) ? c : 0ull;
     }

@@ -855,6 +855,9 @@ int annotate_class(mirge_ctx* c, Class& C, int r, const mirge_round& R) {
 
 template <int KW>
 int counts_class(mirge_ctx* c, Class& C, int M) {
+    uint32_t round_libs = 0;
+    for (int r = 0; r < c->n_rounds; ++r) round_libs |= (uint32_t)(c->rounds[r].lib & 3) << (2 * r);
+    const uint32_t iscan_rounds = c->rounds[0].lib == MIRGE_LIB_MIRNA ? 1u : 0u;      // miRge.pl:472-475: annot 1 only
     for (auto& sg : C.segs) {
         if (!sg.count) continue;
         const size_t lds = M <= CNT_LDS_M ? (size_t)2 * M * 8 : 0;
@@ -862,7 +865,7 @@ int counts_class(mirge_ctx* c, Class& C, int M) {
         uint32_t grid = (uint32_t)std::min<uint64_t>(256 * per_cu, (sg.count + 255) / 256);
         hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(256), lds, C.st, C.coo_g.as<uint32_t>() + sg.start,
                            C.coo_c.as<uint32_t>() + sg.start, (uint32_t)sg.count, sg.sample, c->S, C.ukeys.as<uint64_t>(),
-                           C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), M, 1, 5,
+                           C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), M, round_libs, iscan_rounds,
                            c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu);
     }
     HIPCHK(c, hipGetLastError());

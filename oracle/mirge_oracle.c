@@ -318,7 +318,12 @@ void orc_cascade(orc_lib* const* libs, int64_t U, const char* useqs, const uint6
 void orc_summarize(int64_t U, int32_t S, const uint32_t* counts, const int32_t* ulen,
                    const int8_t* ann_round, const int32_t* ann_ref, int32_t M,
                    uint64_t* quant, uint64_t* iscan, uint64_t* cat, uint64_t* tuniq,
-                   int32_t maxlen, uint64_t* lenhist) {
+                   int32_t maxlen, uint64_t* lenhist, int32_t n_rounds, const int32_t* round_lib) {
+    /* round_lib == NULL: the reference's own five rounds, as miRge.pl:469-489 spells them out (annot 1 / 5 = miRNA,
+     * 2 = hairpin, 3 = other, 4 = mRNA).  round_lib given (a cascade installed through mirge_set_rounds, which the
+     * reference cannot express): the same rule stated by library -- a read's category is the library of the round that
+     * annotated it, only rounds against the miRNA library index quant, only round 1 feeds iscan.  Both agree on the
+     * reference cascade. */
     memset(quant, 0, (size_t)M * S * sizeof(uint64_t));
     memset(iscan, 0, (size_t)M * S * sizeof(uint64_t));
     memset(cat, 0, (size_t)5 * S * sizeof(uint64_t));
@@ -331,6 +336,16 @@ void orc_summarize(int64_t U, int32_t S, const uint32_t* counts, const int32_t* 
             tuniq[s]++;                                            /* :468 */
             if (ulen[u] <= maxlen) lenhist[(int64_t)ulen[u] * S + s] += c;   /* :315 */
             int r = ann_round[u];
+            if (round_lib) {
+                if (r < 1 || r > n_rounds) { cat[4 * S + s] += c; continue; }
+                int lib = round_lib[r - 1];
+                cat[lib * S + s] += c;
+                if (lib == 0) {
+                    quant[(int64_t)ann_ref[u] * S + s] += c;
+                    if (r == 1) iscan[(int64_t)ann_ref[u] * S + s] += c;
+                }
+                continue;
+            }
             if (r == 1 || r == 5) {                                /* :469 */
                 cat[0 * S + s] += c;                               /* :470 mirnaReads */
                 quant[(int64_t)ann_ref[u] * S + s] += c;           /* :473 / :476 */

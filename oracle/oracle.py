@@ -59,7 +59,7 @@ def lib():
         L.orc_cascade.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_summarize.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
-                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         _lib = L
     return _lib
 
@@ -151,8 +151,10 @@ def cascade(libs, useqs, ulens=None, rounds=MIRGE_ROUNDS, use_index=True, nthrea
     return ann_round[:U], ann_ref[:U], ann_amb[:U], stats
 
 
-def summarize(counts, ulen, ann_round, ann_ref, M, maxlen=128):
-    """miRge.pl:465-493.  counts uint32[U, S].  Returns dict of quant/iscan [M,S], cat [5,S], tuniq [S], lenhist."""
+def summarize(counts, ulen, ann_round, ann_ref, M, maxlen=128, rounds=None):
+    """miRge.pl:465-493.  counts uint32[U, S].  Returns dict of quant/iscan [M,S], cat [5,S], tuniq [S], lenhist.
+    rounds: None = the reference's five rounds exactly as the Perl spells them; a list of round tuples = a cascade the
+    reference cannot express (category by the library of the annotating round, see orc_summarize)."""
     counts = np.ascontiguousarray(counts, dtype=np.uint32)
     U, S = counts.shape
     ulen = np.ascontiguousarray(ulen, dtype=np.int32)
@@ -163,7 +165,8 @@ def summarize(counts, ulen, ann_round, ann_ref, M, maxlen=128):
     lenhist = np.zeros((maxlen + 1, S), dtype=np.uint64)
     lib().orc_summarize(U, S, counts.ctypes.data, ulen.ctypes.data, ann_round.ctypes.data, ann_ref.ctypes.data, M,
                         quant.ctypes.data, iscan.ctypes.data, cat.ctypes.data, tuniq.ctypes.data, maxlen,
-                        lenhist.ctypes.data)
+                        lenhist.ctypes.data, 0 if rounds is None else len(rounds),
+                        None if rounds is None else np.array([r[0] for r in rounds], dtype=np.int32).ctypes.data)
     return dict(quant=quant, iscan=iscan, cat=cat, tuniq=tuniq, lenhist=lenhist)
 
 
@@ -189,7 +192,8 @@ def run_path(libs, sample_reads, rounds=MIRGE_ROUNDS, use_index=True, nthreads=1
     uo = offs[rep].astype(np.int64)
     uniques = [text[uo[i]:uo[i] + ulen[i]].tobytes().decode() for i in range(U)]
     ann_round, ann_ref, ann_amb, stats = cascade(libs, uniques, rounds=rounds, use_index=use_index, nthreads=nthreads)
-    out = summarize(counts, ulen, ann_round, ann_ref, libs[0].n, maxlen=maxlen)
+    out = summarize(counts, ulen, ann_round, ann_ref, libs[0].n, maxlen=maxlen,
+                    rounds=None if list(rounds) == list(MIRGE_ROUNDS) else rounds)
     out.update(uniques=uniques, counts=counts, ulen=ulen, ann_round=ann_round, ann_ref=ann_ref, ann_amb=ann_amb,
                stats=stats, uid=uid)
     return out

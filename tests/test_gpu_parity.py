@@ -328,3 +328,36 @@ def test_large_mirna_library_counts_through_global_atomics(oracle):
     assert libs["mirna"].n > 3584
     samples = [synth.make_reads(libs, 60000, 910 + s) for s in range(2)]
     _compare_with_oracle(oracle, libs, samples)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_cascades_vs_oracle(oracle, seed):
+    """Cascades other than miRge's five rounds (the list of rounds is data): random libraries per round,
+    length filters, -5/-3 trimming, seed lengths 5..30, 0..3 seed mismatches, 0..3 mismatches overall (1..4 pieces,
+    cut from the seed or from the whole read), up to 8 rounds -- the device cascade against the oracle's."""
+    rng = np.random.default_rng(1000 + seed)
+    libs, _ = synth.make_libraries(synth.Profile.small(), 300 + seed)
+    samples = [synth.make_reads(libs, 20000, 310 + seed)]
+    seqs, lens = samples[0]
+    for i in rng.integers(0, len(lens), size=300):                       # some reads with N: the 48-byte class
+        seqs[i, int(rng.integers(0, lens[i]))] = ord("N")
+    rounds = []
+    for _ in range(int(rng.integers(2, 9))):
+        len_lt = int(rng.choice([0, 0, 22, 26, 30])); len_gt = int(rng.choice([0, 0, 18, 25]))
+        rounds.append((int(rng.integers(0, 4)), len_lt, len_gt, int(rng.integers(0, 4)), int(rng.integers(0, 4)),
+                       int(rng.choice([5, 8, 12, 15, 20, 28, 30])), int(rng.integers(0, 4)), int(rng.integers(0, 4))))
+    S = 1
+    with capi.Context(None, S, 0) as ctx:
+        util.load_libs_into(ctx, libs)
+        ctx.set_rounds(rounds)
+        ctx.collapse_seqs(seqs, 0, lens)
+        ctx.annotate()
+        got = util.gpu_result_dict(ctx)
+        cv = ctx.counts()
+        stats = [ctx.round_stats(r + 1)[:2] for r in range(len(rounds))]
+    res = oracle.run_path(util.oracle_libs(libs, oracle), samples, rounds=rounds, use_index=True, nthreads=8, maxlen=capi.MAX_READ_LEN)
+    assert got == util.oracle_result_dict(res), rounds
+    for k in ("quant", "iscan", "cat", "tuniq", "lenhist"):       # category = library of the annotating round, quant only from miRNA rounds
+        assert np.array_equal(cv[k], res[k]), (k, rounds)
+    assert stats == [(int(a), int(b)) for a, b in res["stats"]][:len(rounds)], rounds
+    assert sum(b for _, b in stats) > 1000
