@@ -188,10 +188,52 @@ def case_synth(name, profile, n_per_sample, n_samples, seed, mixture=None):
     run_reference(d, name, fq)
 
 
+def case_long(name="synth_long", seed=synth.BASE_SEED + 21):
+    """Reads the trimmed-read mixtures never hold: 5 .. 100 nt (the 48-byte key class for everything over 56 nt, and
+    reads shorter than a seed piece), fragments of every library with 0-2 substitutions, either strand, some N."""
+    d = os.path.join(GOLD, name)
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    libs, merges = synth.make_libraries(synth.Profile.tiny(), seed)
+    synth.write_species_dir(os.path.join(d, "species"), libs, merges, with_dummy_ebwt=False)
+    rng = np.random.default_rng(seed)
+    fq = []
+    for s in range(2):
+        reads = []
+        for _ in range(900):
+            u = rng.random()
+            if u < 0.2:
+                r = "".join("ACGT"[x] for x in rng.integers(0, 4, size=int(rng.integers(5, 101))))
+            else:
+                lib = libs[str(rng.choice(["mirna", "hairpin", "other", "other", "mrna", "mrna"]))]
+                i = int(rng.integers(0, lib.n))
+                ref = lib.text[int(lib.offs[i]):int(lib.offs[i + 1])].tobytes().decode()
+                L = min(len(ref), int(rng.integers(8, 101)))
+                a = int(rng.integers(0, len(ref) - L + 1))
+                r = ref[a:a + L]
+                for _ in range(int(rng.integers(0, 3))):
+                    r = mut(r, int(rng.integers(0, len(r))), rng)
+                if rng.random() < 0.3:
+                    r = rc(r)
+            if rng.random() < 0.03:
+                j = int(rng.integers(0, len(r)))
+                r = r[:j] + "N" + r[j + 1:]
+            reads.append(r)
+        reads += reads[:150]                       # duplicates within the sample
+        rng.shuffle(reads)
+        write_fastq(os.path.join(d, "s%d.fastq" % s), reads)
+        fq.append("s%d.fastq" % s)
+    run_reference(d, name, fq)
+
+
+CASES = {"toy": case_toy,
+         "synth_tiny": lambda: case_synth("synth_tiny", synth.Profile.tiny(), 1500, 3, synth.BASE_SEED + 7),
+         "synth_isomir": lambda: case_synth("synth_isomir", synth.Profile.tiny(), 1200, 2, synth.BASE_SEED + 11, synth.Mixture.isomir_rich()),
+         "synth_long": case_long}
+
 if __name__ == "__main__":
     if not os.path.exists(REF):
         sys.exit("reference not present: fixtures can only be regenerated in the build container")
-    case_toy()
-    case_synth("synth_tiny", synth.Profile.tiny(), 1500, 3, synth.BASE_SEED + 7)
-    case_synth("synth_isomir", synth.Profile.tiny(), 1200, 2, synth.BASE_SEED + 11, synth.Mixture.isomir_rich())
+    for nm in (sys.argv[1:] or list(CASES)):          # no arguments: every case
+        CASES[nm]()
     print("golden fixtures written under", GOLD)
