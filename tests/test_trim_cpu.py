@@ -81,3 +81,27 @@ def test_errors(hostsim):
     assert sim_trim(hostsim, b"@r\n" + b"A" * 125 + b"\n+\n" + b"I" * 125 + b"\n", "none") == -5
     assert sim_trim(hostsim, b"@r\nACGTACGTACGTACGTAXGT\n+\n" + b"I" * 20 + b"\n", "none") == -4
     assert sim_trim(hostsim, b"", "none")[0] == []
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_adapters_lengths_and_cuts(hostsim, seed):
+    """Randomised: 1-3 adapters of 3-32 nt (homopolymers now and then), raw read lengths 20-124, inserts cut short so the
+    adapter starts anywhere (or the read ends inside it), both quality encodings, error and low-quality-tail rates from 0
+    to 1, trim5 / trim3 up to 5.  300 such configurations were run once by hand; ten per seed stay here."""
+    rng = np.random.default_rng(4000 + seed)
+    libs, _ = synth.make_libraries(synth.Profile.tiny(), 77)
+    for _ in range(10):
+        nad = int(rng.integers(1, 4))
+        ads = ["".join("ACGT"[x] for x in rng.integers(0, 4, size=int(rng.integers(3, 33)))) for _ in range(nad)]
+        ads = [a[0] * len(a) if rng.random() < 0.1 else a for a in ads]
+        adapter = ",".join(ads)
+        t5, t3 = int(rng.integers(0, 6)), int(rng.integers(0, 6))
+        seqs, lens = synth.make_reads(libs, 300, int(rng.integers(0, 1 << 30)))
+        lens = np.minimum(lens, rng.integers(1, 48, size=len(lens))).astype(lens.dtype)
+        data = synth.make_raw_fastq(seqs, lens, int(rng.integers(0, 1 << 30)), adapter=ads[int(rng.integers(0, nad))],
+                                    read_len=int(rng.choice([20, 36, 50, 75, 100, 124])), phred=int(rng.choice([33, 64])),
+                                    adapter_error=float(rng.random()), low_tail=float(rng.random()))
+        want, total, base, reported = otrim.trim_fastq(data, adapter, t5, t3)
+        got = sim_trim(hostsim, data, adapter, t5, t3)
+        assert not isinstance(got, int), (got, adapter)
+        assert (got[0], got[1], got[2], got[3]) == (want, total, base, reported), (adapter, t5, t3)
