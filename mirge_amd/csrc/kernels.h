@@ -106,12 +106,11 @@ k_pack(const uint8_t* __restrict__ seqs, uint32_t width, const uint8_t* __restri
 template <int KW, int T, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 k_collapse_local(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ wt, uint32_t n, uint32_t* lslots, uint32_t lmask,
-                 uint32_t* cnt, uint32_t* cnt0, uint32_t* rep_out) {
+                 uint32_t* cnt, uint32_t* cnt0) {
     // wt (nullable): a count per input key (records merged from other ranks, shard.h); null = one read each
     __shared__ uint64_t tk[T * KW];
     __shared__ uint32_t towner[2 * T];
     __shared__ uint32_t tcnt[T];
-    __shared__ uint32_t tglob[T];
     constexpr int PER = T / BLOCK;
     const uint32_t base = blockIdx.x * (uint32_t)T;
     const uint32_t tid = threadIdx.x;
@@ -170,7 +169,6 @@ k_collapse_local(const uint64_t* __restrict__ keys, const uint32_t* __restrict__
             }
             if (claimed) mine[e] = tcnt[idx];                   // the claimant's own count: a plain store below
             else atomicAdd(&cnt[g], tcnt[idx]);
-            tglob[idx] = g;
         }
     }
 #pragma unroll
@@ -178,21 +176,12 @@ k_collapse_local(const uint64_t* __restrict__ keys, const uint32_t* __restrict__
         uint32_t idx = tid + e * BLOCK;
         if (idx < nvalid) cnt0[base + idx] = mine[e];           // 0 for every read that is not a representative
     }
-    if (rep_out) {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            uint32_t idx = tid + e * BLOCK;
-            if (idx < nvalid) rep_out[base + idx] = tglob[trep[e]];
-        }
-    }
 }
 
 // collapse, step B: every representative read (cnt > 0) becomes one (unique id, count) entry of
 // this sample.  If a table of earlier samples' uniques exists (gslots != null) it is looked up
 // first (read-only here); unseen keys are appended to ukeys at U0 + atomic rank.
-// ctr[0] = (new uniques appended << 32) | entries emitted.  gid_of (nullable): unique id per
-// representative read index.
+// ctr[0] = (new uniques appended << 32) | entries emitted.
 // A single hot counter takes ~12 ns per atomic on this chip, so ranks are formed per 2048-element tile
 // (block scan in LDS) and each tile costs one atomic.
 constexpr int EMIT_PER = 8;
@@ -200,7 +189,7 @@ template <int KW>
 __global__ void __launch_bounds__(256)
 k_collapse_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cnt0, uint32_t n,
                 const uint32_t* __restrict__ gslots, uint32_t gmask, uint64_t* ukeys, uint32_t U0,
-                uint32_t* coo_g, uint32_t* coo_c, unsigned long long* ctr, uint32_t* gid_of) {
+                uint32_t* coo_g, uint32_t* coo_c, unsigned long long* ctr) {
     __shared__ uint32_t s_scan[256];
     __shared__ uint32_t s_base[2];
     const uint32_t tid = threadIdx.x;
@@ -265,7 +254,6 @@ k_collapse_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ 
         coo_g[prep] = gg;
         coo_c[prep] = c[e];
         ++prep;
-        if (gid_of) gid_of[i] = gg;
     }
 }
 
@@ -284,13 +272,6 @@ k_gtable_insert(const uint64_t* __restrict__ ukeys, uint32_t g0, uint32_t g1, ui
         if (atomicCAS(&gslots[h], EMPTY, g) == EMPTY) break;
         h = (h + 1) & gmask;
     }
-}
-
-// per-read unique id: uid[i] = gid_of[rep[i]]
-__global__ void __launch_bounds__(256)
-k_uid(const uint32_t* __restrict__ rep, const uint32_t* __restrict__ gid_of, uint32_t n, uint32_t* uid, uint32_t flag) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) uid[i] = gid_of[rep[i]] | flag;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -121,7 +121,7 @@ struct mirge_ctx {
     mirge_round rounds[MIRGE_MAX_ROUNDS];
     Class cls[2];                                   // [0] 16-byte keys, [1] 48-byte keys
     // workspaces
-    DevBuf rep, ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist;
+    DevBuf ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist;
     DevBuf sh_ctr, sh_w[2];                         // multi-GPU exchange: per-owner / per-sample counters, weights of imported records
     int sh_world = 0; uint64_t sh_n[2][SHARD_MAX_WORLD] = {};
     DevBuf fq_raw, fq_seg, fq_segb, fq_start, fq_qstart, fq_qend;       // FASTQ ingest: raw file bytes, newline counts per segment (+ scanned), record starts
@@ -362,14 +362,14 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
     constexpr int CB = KW == 2 ? MG_CL_B : 256;
     kt_begin(c, tagA, st);
     hipLaunchKernelGGL((k_collapse_local<KW, T, CB>), dim3((n + T - 1) / T), dim3(CB), 0, st,
-                       d_keys, d_wt, n, C.ws_lslots.as<uint32_t>(), (uint32_t)(capL - 1), C.ws_cnt.as<uint32_t>(), C.ws_cnt0.as<uint32_t>(), (uint32_t*)nullptr);
+                       d_keys, d_wt, n, C.ws_lslots.as<uint32_t>(), (uint32_t)(capL - 1), C.ws_cnt.as<uint32_t>(), C.ws_cnt0.as<uint32_t>());
     kt_end(c, tagA, (uint64_t)n * KW * 8, st);
     kt_begin(c, tagB, st);
     hipLaunchKernelGGL((k_collapse_emit<KW>), dim3((n + 256 * EMIT_PER - 1) / (256 * EMIT_PER)), dim3(256), 0, st,
                        d_keys, C.ws_cnt.as<uint32_t>(), C.ws_cnt0.as<uint32_t>(), n, use_g ? C.gslots.as<uint32_t>() : (const uint32_t*)nullptr,
                        (uint32_t)(C.gcap ? C.gcap - 1 : 0), C.ukeys.as<uint64_t>(), (uint32_t)C.U,
                        C.coo_g.as<uint32_t>() + C.coo_n, C.coo_c.as<uint32_t>() + C.coo_n,
-                       C.ws_ctr.as<unsigned long long>(), (uint32_t*)nullptr);
+                       C.ws_ctr.as<unsigned long long>());
     kt_end(c, tagB, 0, st);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(C.h_ctr, C.ws_ctr.p, 16, hipMemcpyDeviceToHost, st));
@@ -1087,7 +1087,7 @@ void mirge_close(mirge_ctx* c) {
     if (c->st2) (void)hipStreamSynchronize(c->st2);
     for (auto& L : c->libs) L.release();
     for (auto& C : c->cls) C.release();
-    DevBuf* ws[] = {&c->rep, &c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
+    DevBuf* ws[] = {&c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
                     &c->fq_raw, &c->fq_seg, &c->fq_segb, &c->fq_start, &c->fq_qstart, &c->fq_qend, &c->sh_ctr, &c->sh_w[0], &c->sh_w[1], &c->hist, &c->state};
     for (auto* b : ws) b->release();
     for (auto& k : c->kt) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
