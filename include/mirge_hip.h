@@ -133,6 +133,19 @@ int32_t     mirge_pack_dev(mirge_ctx*, const void* d_seqs, uint32_t width, const
 int32_t     mirge_collapse_packed_dev(mirge_ctx*, const void* d_keys16, uint64_t n16,
                                       const void* d_keys48, uint64_t n48, int32_t sample);
 
+/* NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate device memory -- code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc: the collapse step of mirge_collapse_packed_dev for one stream
+ * of n 16-byte keys, with every workspace of its kernels (slot table, duplicate counters, ranks) in a fixed array
+ * inside the library (about 20 MB, held by every GPU the library runs on until the process ends) and the results in the
+ * caller's buffers: d_ukeys receives the distinct keys (room for n x 16 bytes), d_counts[j] the number of input keys
+ * equal to d_ukeys[j] (room for n), *n_unique how many there are; their order is unspecified.  The context's table is
+ * not touched.  The call allocates and frees nothing (no hipMalloc / hipFree, no stream or event creation); it ends
+ * with one stream synchronise to hand back n_unique.  n > MIRGE_NOALLOC_MAX_KEYS fails with MIRGE_E_LIMIT.  All calls
+ * on one GPU -- from any context, any thread -- share that GPU's array: calls that overlap on one GPU race. */
+#define MIRGE_NOALLOC_MAX_KEYS (1u << 20)
+int32_t     mirge_collapse_keys16_noalloc(mirge_ctx*, const void* d_keys16, uint64_t n, void* d_ukeys, uint32_t* d_counts,
+                                          uint64_t* n_unique);
+
 /* ---- cascade (replaces the loop of miRge.pl:346-371: writeSeqToAnnot,
  *      system(bowtie), parseBowtieLog, parseAlignment, updateAnnotHash) ----- */
 int32_t     mirge_annotate(mirge_ctx*);

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("MIRGE_HIP_LIB") or os.path.join(HERE, "libmirge_hip.s
 LIB_MIRNA, LIB_HAIRPIN, LIB_OTHER, LIB_MRNA = 0, 1, 2, 3
 MAX_ROUNDS = 8
 MAX_READ_LEN = 124
+NOALLOC_MAX_KEYS = 1 << 20
 
 EXPORTS = [
     "mirge_open", "mirge_close", "mirge_last_error", "mirge_reset", "mirge_load_library_fasta", "mirge_load_library_ebwt",
@@ -26,6 +27,7 @@ EXPORTS = [
     "mirge_collapse_packed_dev", "mirge_annotate", "mirge_round_stats", "mirge_counts", "mirge_counts_flat_len",
     "mirge_counts_flat_get", "mirge_counts_flat_set", "mirge_n_unique", "mirge_unique", "mirge_export_uniques",
     "mirge_n_counts", "mirge_export_counts", "mirge_last_timing", "mirge_kernel_times", "mirge_write_tables",
+    "mirge_collapse_keys16_noalloc",
 ]
 
 
@@ -85,6 +87,7 @@ def load():
     L.mirge_collapse_ascii_dev.argtypes = [vp, vp, u32, vp, u64, i32]
     L.mirge_pack_dev.argtypes = [vp, vp, u32, vp, u64, vp, C.POINTER(u64), vp, C.POINTER(u64)]
     L.mirge_collapse_packed_dev.argtypes = [vp, vp, u64, vp, u64, i32]
+    L.mirge_collapse_keys16_noalloc.argtypes = [vp, vp, u64, vp, vp, C.POINTER(u64)]
     L.mirge_annotate.argtypes = [vp]
     L.mirge_round_stats.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
     L.mirge_counts.argtypes = [vp] + [C.POINTER(C.POINTER(u64))] * 5
@@ -242,6 +245,12 @@ class Context:
 
     def collapse_packed_dev(self, d_keys16, n16, d_keys48, n48, sample):
         self._chk(self.L.mirge_collapse_packed_dev(self.h, d_keys16, n16, d_keys48, n48, sample))
+
+    def collapse_keys16_noalloc(self, d_keys16, n, d_ukeys, d_counts):
+        """The no-allocation collapse of one 16-byte key stream into caller buffers -> number of distinct keys."""
+        u = C.c_uint64(0)
+        self._chk(self.L.mirge_collapse_keys16_noalloc(self.h, d_keys16, n, d_ukeys, d_counts, C.byref(u)))
+        return u.value
 
     # ---- cascade + counts
     def annotate(self):

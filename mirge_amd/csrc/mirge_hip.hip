@@ -57,6 +57,35 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// ---- workspace of the one entry point that allocates nothing (mirge_collapse_keys16_noalloc).  A fixed array in the
+// code object: every GPU the library runs on holds its own copy, at its own address, until the process ends.  Host code
+// never passes the array's NAME to a kernel or a memset (on the host that name is a stand-in, not a device address): the
+// address of the current device's copy is asked for once per device (na_scratch_init, called by mirge_open) and kept.
+constexpr uint64_t NA_MAX_KEYS = MIRGE_NOALLOC_MAX_KEYS;
+constexpr uint64_t NA_SLOTS = 2 * NA_MAX_KEYS;                  // power of two >= 1.25 * NA_MAX_KEYS: load <= 0.5 at the maximum
+struct NaLayout {
+    uint32_t lslots[NA_SLOTS];                                  // k_collapse_local's open-addressing table
+    uint32_t cnt[NA_MAX_KEYS], cnt0[NA_MAX_KEYS];               // duplicate adds / the claimant's own count per input key
+    uint32_t coo_g[NA_MAX_KEYS];                                // k_collapse_emit's unique ids (0, 1, 2, ... here: nothing is known beforehand)
+    unsigned long long ctr[32];                                 // k_collapse_emit's packed rank counter
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(NaLayout)];
+constexpr int NA_MAX_DEVICES = 64;
+std::mutex g_na_mu;
+NaLayout* g_na_ptr[NA_MAX_DEVICES] = {};                        // per device: where that GPU's copy of `scratch` lives
+// with `device` current
+hipError_t na_scratch_init(int device) {
+    if (device < 0 || device >= NA_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_na_mu);
+    if (g_na_ptr[device]) return hipSuccess;
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_na_ptr[device] = reinterpret_cast<NaLayout*>(p);
+    return hipSuccess;
+}
+
 struct Lib {
     bool loaded = false;
     std::vector<std::string> names, short_names;
@@ -1035,6 +1064,9 @@ mirge_ctx* mirge_open(const char* species_dir, int32_t n_samples, int32_t device
     }
     if (device < 0 || device >= ndev) { fail(nullptr, MIRGE_E_ARG, "device index out of range"); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { fail(nullptr, MIRGE_E_HIP, "hipSetDevice failed"); return nullptr; }
+    if (hipError_t ne = na_scratch_init(device); ne != hipSuccess) {
+        fail(nullptr, MIRGE_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(ne)); return nullptr;
+    }
     mirge_ctx* c = new mirge_ctx();
     c->device = device; c->S = n_samples;
     c->cls[0].KW = 2; c->cls[1].KW = 6;
@@ -1273,6 +1305,41 @@ int32_t mirge_collapse_packed_dev(mirge_ctx* c, const void* d16, uint64_t n16, c
     if (!c || (n16 && !d16) || (n48 && !d48)) return c ? fail(c, MIRGE_E_ARG, "null device pointer") : MIRGE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     return collapse_packed(c, d16, n16, d48, n48, sample);
+}
+
+// The collapse of ONE stream of 16-byte keys with nothing allocated: the kernels of mirge_collapse_packed_dev, their
+// workspaces in this GPU's copy of `scratch`, the results in the caller's buffers.  No hipMalloc / hipFree / event or
+// stream creation on this path (the stream and the pinned word it reads the result through were made by mirge_open).
+int32_t mirge_collapse_keys16_noalloc(mirge_ctx* c, const void* d_keys16, uint64_t n, void* d_ukeys, uint32_t* d_counts, uint64_t* n_unique) {
+    if (!c) return MIRGE_E_ARG;
+    if (!n_unique || (n && (!d_keys16 || !d_ukeys || !d_counts))) return fail(c, MIRGE_E_ARG, "null pointer");
+    if (n > NA_MAX_KEYS)
+        return fail(c, MIRGE_E_LIMIT, "mirge_collapse_keys16_noalloc takes at most " + std::to_string(NA_MAX_KEYS) + " keys per call (" +
+                                          std::to_string(n) + " given): its workspace is a fixed array");
+    if (((uintptr_t)d_keys16 | (uintptr_t)d_ukeys) & 7) return fail(c, MIRGE_E_ARG, "key buffers must be 8-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    NaLayout* W = (c->device >= 0 && c->device < NA_MAX_DEVICES) ? g_na_ptr[c->device] : nullptr;
+    if (!W) return fail(c, MIRGE_E_HIP, "no workspace address for this device");
+    *n_unique = 0;
+    if (n == 0) return MIRGE_OK;
+    const uint32_t n32 = (uint32_t)n;
+    const uint64_t cap = pow2_at_least(n + n / 4);              // <= NA_SLOTS
+    // the array keeps the last call's contents: everything that must start out empty / zero is cleared here
+    HIPCHK(c, hipMemsetAsync(W->lslots, 0xFF, cap * 4, c->st));
+    HIPCHK(c, hipMemsetAsync(W->cnt, 0, n * 4, c->st));
+    HIPCHK(c, hipMemsetAsync(W->ctr, 0, sizeof W->ctr, c->st));
+    constexpr int T = MG_CL_T, CB = MG_CL_B;
+    hipLaunchKernelGGL((k_collapse_local<2, T, CB>), dim3((n32 + T - 1) / T), dim3(CB), 0, c->st, (const uint64_t*)d_keys16,
+                       (const uint32_t*)nullptr, n32, W->lslots, (uint32_t)(cap - 1), W->cnt, W->cnt0);
+    hipLaunchKernelGGL((k_collapse_emit<2>), dim3((n32 + 256 * EMIT_PER - 1) / (256 * EMIT_PER)), dim3(256), 0, c->st,
+                       (const uint64_t*)d_keys16, W->cnt, W->cnt0, n32, (const uint32_t*)nullptr, 0u, (uint64_t*)d_ukeys, 0u,
+                       W->coo_g, d_counts, W->ctr);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr + 10, W->ctr, 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    // no earlier table: every representative is a new unique, so entry j of the counts belongs to unique j
+    *n_unique = c->h_ctr[10] >> 32;
+    return MIRGE_OK;
 }
 
 int32_t mirge_annotate(mirge_ctx* c) {
