@@ -36,6 +36,13 @@ struct LibDev {
     uint32_t n_refs;
     uint32_t T;                  // text length in nt, separators included
     int32_t  kb;
+    // gapped seed indexes (see gap_code): two more CSR indexes over every text position, bucket = kbg of the 12 nt that a
+    // 3-of-4-blocks shape selects from text[p, p+16).  Their entries live in kent / kpre behind the contiguous index's,
+    // so a candidate list is a range of the same arrays whichever index it came from.
+    const uint32_t* koffg;       // 2 x (gbk + 1) offsets into kent / kpre (absolute)
+    const uint32_t* kbitsg;      // 2 x gbk / 32 occupancy words
+    uint32_t gbk;                // buckets per gapped index = 4^kbg
+    int32_t  kbg;                // 0 = no gapped indexes
 };
 
 struct RoundDev { int32_t lib, len_lt, len_gt, trim5, trim3, seedlen, seedmm, maxmm; };
@@ -283,10 +290,25 @@ MG_HD uint32_t text_kmer(const uint64_t* __restrict__ text, uint32_t p, int kb) 
     v &= ones(2 * kb);
     return (uint32_t)(rev2(v) >> (64 - 2 * kb));
 }
+// Gapped seeds.  A read whose seed is shorter than two index k-mers cannot be cut into two exact-lookup pieces: a
+// 16-nt seed against a kb = 12 index gives two 8-nt pieces, each a RANGE of 256 buckets (~55 candidates per lookup in
+// a 3.6 Mnt library).  Instead the first 16 seed nt are cut into four 4-nt blocks: with <= 1 mismatch among them three
+// blocks are exact, so the four shapes 1110, 0111, 1101, 1011 (1 = block used) between them find every such alignment,
+// each through ONE bucket of 12-nt specificity.  1110 and 0111 are contiguous 12-mers (the ordinary index at offsets 0
+// and 4); 1101 and 1011 are the two gapped indexes.  c16 = the 16-nt window as the TEXT holds it, first nt most
+// significant; g = 0: shape 1101, g = 1: shape 1011; the result is the 24-bit code of the 12 selected nt.
+MG_HD uint32_t gap_code(uint32_t c16, int g) {
+    return g == 0 ? (((c16 >> 8) & 0xFFFF00u) | (c16 & 0xFFu)) : (((c16 >> 8) & 0xFF0000u) | (c16 & 0xFFFFu));
+}
+// bucket of text position p: shape 0 = the contiguous kb-mer, shape 1 / 2 = gapped index g = shape - 1 (k = kbg)
+MG_HD uint32_t index_bucket(const uint64_t* __restrict__ text, uint32_t p, int k, int shape) {
+    if (shape == 0) return text_kmer(text, p, k);
+    return gap_code(text_kmer(text, p, 16), shape - 1) >> (2 * (12 - k));
+}
 __global__ void __launch_bounds__(256)
-k_kmer_hist(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* hist) {
+k_kmer_hist(const uint64_t* __restrict__ text, uint32_t T, int kb, int shape, uint32_t* hist) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < T) atomicAdd(&hist[text_kmer(text, p, kb)], 1u);
+    if (p < T) atomicAdd(&hist[index_bucket(text, p, kb, shape)], 1u);
 }
 MG_HD KEnt make_kent(const uint64_t* __restrict__ text, uint32_t p) {
     // 96 bits of text starting at nt p - CTX_BACK (zeros for nt before the text starts)
@@ -310,11 +332,11 @@ MG_HD KEnt make_kent(const uint64_t* __restrict__ text, uint32_t p) {
 constexpr int PRE_SKIP = 4;
 MG_HD uint64_t make_kpre(const KEnt& e) { return ((((uint64_t)e.c0 | ((uint64_t)e.c1 << 32)) >> (2 * PRE_SKIP)) | ((uint64_t)e.c2 << (64 - 2 * PRE_SKIP))); }
 __global__ void __launch_bounds__(256)
-k_kmer_scatter(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* cursor, KEnt* kent, uint64_t* kpre) {
+k_kmer_scatter(const uint64_t* __restrict__ text, uint32_t T, int kb, int shape, uint32_t* cursor, KEnt* kent, uint64_t* kpre) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < T) {
         const KEnt e = make_kent(text, p);
-        const uint32_t at = atomicAdd(&cursor[text_kmer(text, p, kb)], 1u);
+        const uint32_t at = atomicAdd(&cursor[index_bucket(text, p, kb, shape)], 1u);
         kent[at] = e; kpre[at] = make_kpre(e);
     }
 }
@@ -661,6 +683,46 @@ MG_HD void koff_range(const LibDev& L, uint64_t b0, uint64_t b1, uint32_t& lo, u
     }
 }
 
+// Does this read go through the gapped seeds?  Only where two pieces would be range queries: a round of two pieces
+// (<= 1 mismatch guaranteed among the first 16 nt: they lie inside the seed, or the whole read holds <= 1), a seed of
+// >= 16 nt, pieces shorter than the index k-mer, and a library that carries the gapped indexes.
+template <int SW> MG_HD bool read_gapped(const LibDev& L, const RoundDev& P, const Query<SW>& Q) {
+    return L.kbg > 0 && round_np(P) == 2 && Q.ok && Q.s >= 16 && piece_cut(Q.span, 1, 2) < L.kb;
+}
+// lookups a read of this round makes at most (wave-uniform): four shapes where gapped reads can occur
+MG_HD int round_nlook(const LibDev& L, const RoundDev& P) { return (L.kbg > 0 && round_np(P) == 2) ? 4 : round_np(P); }
+// Shape 0 (blocks 0-2 exact) finds every alignment without a mismatch in the first 12 seed nt, so in particular every
+// alignment of stratum 0: once one is known the other shapes can only add worse strata.
+MG_HD bool gap_needed(uint64_t score) { return score == 0 || 4 - (int)(score >> 36) >= 1; }
+// Lookup p of a prepared read on strand f -> candidate list [lo, hi) of kent / kpre and the position qs (oriented read)
+// of the window whose text position the entries carry.  Regular reads: piece p of np.  Gapped reads: p = 0 / 1 the
+// contiguous 12-mers at seed offsets 0 / 4 (ordinary index), p = 2 / 3 the gapped indexes 0 / 1.  On the reverse strand
+// the text holds the reverse complement of the 16-nt window, so its shape is mirrored (1101 <-> 1011): index g then
+// covers the OTHER read shape, and the two lookups p = 2, 3 still cover both.
+template <int SW, bool HASN>
+MG_HD void lookup_range(const Query<SW>& Q, const LibDev& L, bool gap, int np, int p, int f, int& qs, uint32_t& lo, uint32_t& hi) {
+    lo = 0; hi = 0; qs = 0;
+    if (gap && p >= 2) {
+        const int g = p - 2;
+        // the read blocks the shape selects must hold no N (bit i of the mask = read nt i; blocks 0,1,3 or 0,2,3)
+        if (HASN && ((uint32_t)Q.q[1].n[0] & (f != g ? 0xF0FFu : 0xFF0Fu))) return;
+        const uint32_t v = (uint32_t)Q.q[1].s[0];                      // first 16 nt of the forward read, nt 0 in the low bits
+        const uint32_t c16 = f ? (uint32_t)(rev2((uint64_t)v) >> 32) : ~v;
+        const uint32_t b = gap_code(c16, g) >> (2 * (12 - L.kbg));
+        qs = f ? 0 : Q.l - 16;
+        if (L.kbitsg && !((L.kbitsg[(uint32_t)g * (L.gbk >> 5) + (b >> 5)] >> (b & 31)) & 1)) return;
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+        const u32x2 o = *reinterpret_cast<const u32x2*>(L.koffg + (size_t)g * (L.gbk + 1) + b);
+        lo = o.x; hi = o.y;
+        return;
+    }
+    int ps, pe;
+    if (gap) { ps = p ? 4 : 0; pe = p ? 16 : 12; }
+    else { if (p >= np) return; ps = piece_cut(Q.span, p, np); pe = piece_cut(Q.span, p + 1, np); }
+    uint64_t b0, b1;
+    if (piece_buckets_fwd<SW, HASN>(Q.q[1], Q.l, L.kb, f, ps, pe, qs, b0, b1)) koff_range(L, b0, b1, lo, hi);
+}
+
 // Serial form of the matcher (one read, all candidates in turn): the definition the kernel below
 // parallelises, and what tests/hostsim runs on the CPU.
 template <int KW>
@@ -671,19 +733,22 @@ __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, 
     query_setup<KW>(key, P, Q);
     if (!Q.ok) return false;
     const int np = round_np(P);
+    const bool gap = read_gapped<SW>(L, P, Q);
+    const int nlook = gap ? 4 : np;
     uint64_t score = 0, kmax = 0, kmin = 0;
-    for (int p = 0; p < np; ++p) {
-        if (!piece_needed(P, p, score)) break;                  // as the kernel: decided once per piece, before either strand
+    for (int p = 0; p < nlook; ++p) {
+        if (p && !(gap ? gap_needed(score) : piece_needed(P, p, score))) break;    // as the kernel: decided once per lookup, before either strand
         for (int fw = 1; fw >= 0; --fw) {
             const Oriented<SW>& o = Q.q[fw];
             Strand<SW, HASN> S;
             strand_setup<SW, HASN>(o, fw, Q.l, Q.s, P, S);
             if (!S.ok) continue;
-            int qs; uint64_t b0, b1;
-            if (!piece_buckets_fwd<SW, HASN>(Q.q[1], Q.l, L.kb, fw, piece_cut(Q.span, p, np), piece_cut(Q.span, p + 1, np), qs, b0, b1)) continue;
+            int qs; uint32_t lo, hi;
+            lookup_range<SW, HASN>(Q, L, gap, np, p, fw, qs, lo, hi);
+            if (lo == hi) continue;
             PieceAl A;
             piece_align<SW, HASN>(o, S, qs, fw, 0u, A);
-            koff_range(L, b0, b1, A.lo, A.hi);
+            A.lo = lo; A.hi = hi;
             const bool scan = A.hi - A.lo > 8;                  // as the kernel: long lists go through the pre-filter
             const PreAl R = pre_of(A);
             for (uint32_t c = A.lo; c < A.hi; ++c) {
@@ -821,16 +886,17 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         sok[f] = Q.ok;       // (the N counts of a read and of its seed are the same on both strands)
         if (HASN) { Strand<SW, HASN> T; strand_setup<SW, HASN>(Q.q[1], 1, Q.l, Q.s, P, T); sok[f] = sok[f] && T.ok; }
     }
-    for (int p = 0; p < np; ++p) {
-        const int ps = piece_cut(Q.span, p, np), pe = piece_cut(Q.span, p + 1, np);
+    const bool gap = read_gapped<SW>(L, P, Q);
+    const int nlook = round_nlook(L, P);
+    for (int p = 0; p < nlook; ++p) {
         uint32_t lo[2], hi[2]; int qs[2];
         // what this thread checked itself is in s_best[tid] by now (queued lists are not: they can only add hits)
-        const bool need = p == 0 || piece_needed(P, p, s_best[tid]);
+        const bool need = p == 0 || (gap ? gap_needed(s_best[tid]) : (p < np && piece_needed(P, p, s_best[tid])));
+        if (p >= np && !__any(gap && need)) break;       // lookups 2, 3 exist for gapped reads only
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            uint64_t b0 = 0, b1 = 0;
             lo[f] = 0; hi[f] = 0; qs[f] = 0;
-            if (need && sok[f] && piece_buckets_fwd<SW, HASN>(Q.q[1], Q.l, L.kb, f, ps, pe, qs[f], b0, b1)) koff_range(L, b0, b1, lo[f], hi[f]);
+            if (need && sok[f]) lookup_range<SW, HASN>(Q, L, gap, np, p, f, qs[f], lo[f], hi[f]);
         }
 #pragma unroll
         for (int f = 0; f < 2; ++f) {

@@ -94,15 +94,17 @@ struct Lib {
     int kb = 0;
     DevBuf text, bad, koff, kent, kpre, kbits, dref, dlut; int lut_shift = 5;
     bool use_bits = true;                // false: koff is small enough to stay in L2, the occupancy bitmap is skipped
+    DevBuf koffg, kbitsg; int kbg = 0; uint32_t gbk = 0; bool use_bits_g = true;     // gapped seed indexes (built on first use: ensure_gapped)
     LibDev dev() const {
         LibDev L;
         L.text = text.as<uint64_t>(); L.bad = bad.as<uint64_t>(); L.koff = koff.as<uint32_t>();
         L.kent = kent.as<KEnt>(); L.kpre = kpre.as<uint64_t>(); L.kbits = use_bits ? kbits.as<uint32_t>() : nullptr; L.ref_start = dref.as<uint32_t>();
         L.ref_lut = dlut.as<uint32_t>(); L.lut_shift = lut_shift;
         L.n_refs = (uint32_t)names.size(); L.T = (uint32_t)T; L.kb = kb;
+        L.koffg = koffg.as<uint32_t>(); L.kbitsg = (kbg && use_bits_g) ? kbitsg.as<uint32_t>() : nullptr; L.gbk = gbk; L.kbg = kbg;
         return L;
     }
-    void release() { text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); loaded = false; }
+    void release() { text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); koffg.release(); kbitsg.release(); kbg = 0; loaded = false; }
 };
 
 constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
@@ -257,7 +259,7 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     for (auto& nm : L.names) { size_t e = nm.find_first_of(" \t"); L.short_names.push_back(e == std::string::npos ? nm : nm.substr(0, e)); }
     int kb = (int)std::lround(std::log2((double)std::max<uint64_t>(T, 16)) / 2.0) + 1;   // ~0.25 random entries per bucket
     L.kb = std::min(14, std::max(4, kb));
-    L.use_bits = true;
+    L.use_bits = true; L.kbg = 0; L.gbk = 0;
     if (const char* env = getenv("MIRGE_KB_BIAS")) L.kb = std::min(14, std::max(4, L.kb + atoi(env)));   // tuning aid
     if (const char* env = getenv("MIRGE_KB")) { if (atoi(env) >= 2 && atoi(env) <= 15) L.kb = atoi(env); }   // tests
     uint64_t nb = 1ull << (2 * L.kb);
@@ -286,12 +288,12 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (nb + 1) * 4, c->st));
     if (T > 0) {
         uint32_t grid = (uint32_t)((T + 255) / 256);
-        hipLaunchKernelGGL(k_kmer_hist, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, c->hist.as<uint32_t>());
+        hipLaunchKernelGGL(k_kmer_hist, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, 0, c->hist.as<uint32_t>());
         hipLaunchKernelGGL(k_bucket_bits, dim3((uint32_t)((nb / 32 + 256) / 256)), dim3(256), 0, c->st, c->hist.as<uint32_t>(), nb, L.kbits.as<uint32_t>());
         int rc = scan_exclusive(c, c->hist.as<uint32_t>(), L.koff.as<uint32_t>(), nb + 1);
         if (rc) return rc;
         HIPCHK(c, hipMemcpyAsync(c->hist.p, L.koff.p, nb * 4, hipMemcpyDeviceToDevice, c->st));
-        hipLaunchKernelGGL(k_kmer_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, c->hist.as<uint32_t>(), L.kent.as<KEnt>(), L.kpre.as<uint64_t>());
+        hipLaunchKernelGGL(k_kmer_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, 0, c->hist.as<uint32_t>(), L.kent.as<KEnt>(), L.kpre.as<uint64_t>());
         HIPCHK(c, hipGetLastError());
     } else {
         HIPCHK(c, hipMemsetAsync(L.koff.p, 0, (nb + 1) * 4, c->st));
@@ -299,6 +301,47 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     HIPCHK(c, hipStreamSynchronize(c->st));
     L.loaded = true;
     c->annotated = false; c->counts_valid = false; c->host_valid = false;
+    return MIRGE_OK;
+}
+
+// The two gapped seed indexes of a library (kernels.h: gap_code), built the first time a cascade holds a round that
+// can use them -- a two-piece round (<= 1 seed mismatch) against a library whose index k-mer is longer than half a
+// 16-nt seed.  Their entries go behind the contiguous index's in kent / kpre.
+__global__ void __launch_bounds__(256) k_add_u32(uint32_t* a, uint64_t n, uint32_t v) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += v;
+}
+int ensure_gapped(mirge_ctx* c, Lib& L) {
+    if (L.kbg || !L.loaded || L.kb < 9 || L.T == 0 || 3 * L.T >= 0xFFFFFFF0ull) return MIRGE_OK;
+    if (const char* env = getenv("MIRGE_GAPPED")) { if (atoi(env) == 0) return MIRGE_OK; }      // A/B aid
+    const int kbg = std::min(L.kb, 12);
+    const uint64_t gbk = 1ull << (2 * kbg), T = L.T;
+    HIPCHK(c, L.kent.ensure(3 * T * sizeof(KEnt), true, T * sizeof(KEnt), c->st));
+    HIPCHK(c, L.kpre.ensure(3 * T * 8, true, T * 8, c->st));
+    HIPCHK(c, L.koffg.ensure(2 * (gbk + 1) * 4, false, 0, c->st));
+    HIPCHK(c, L.kbitsg.ensure(2 * (gbk / 32) * 4 + 4, false, 0, c->st));
+    HIPCHK(c, c->hist.ensure((gbk + 1) * 4, false, 0, c->st));
+    HIPCHK(c, hipMemsetAsync(L.kbitsg.p, 0, 2 * (gbk / 32) * 4 + 4, c->st));
+    const uint32_t grid = (uint32_t)((T + 255) / 256);
+    for (int g = 0; g < 2; ++g) {
+        uint32_t* ko = L.koffg.as<uint32_t>() + (size_t)g * (gbk + 1);
+        HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (gbk + 1) * 4, c->st));
+        hipLaunchKernelGGL(k_kmer_hist, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, kbg, g + 1, c->hist.as<uint32_t>());
+        hipLaunchKernelGGL(k_bucket_bits, dim3((uint32_t)((gbk / 32 + 256) / 256)), dim3(256), 0, c->st, c->hist.as<uint32_t>(), gbk,
+                           L.kbitsg.as<uint32_t>() + (size_t)g * (gbk / 32));
+        int rc = scan_exclusive(c, c->hist.as<uint32_t>(), ko, gbk + 1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_add_u32, dim3((uint32_t)((gbk + 1 + 255) / 256)), dim3(256), 0, c->st, ko, gbk + 1, (uint32_t)((g + 1) * T));
+        HIPCHK(c, hipMemcpyAsync(c->hist.p, ko, gbk * 4, hipMemcpyDeviceToDevice, c->st));
+        hipLaunchKernelGGL(k_kmer_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, kbg, g + 1, c->hist.as<uint32_t>(),
+                           L.kent.as<KEnt>(), L.kpre.as<uint64_t>());
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    uint64_t lim = 8ull << 20;
+    if (const char* env = getenv("MIRGE_BITS_ABOVE")) lim = strtoull(env, nullptr, 10);
+    L.use_bits_g = gbk * 4 > lim;
+    L.kbg = kbg; L.gbk = (uint32_t)gbk;
     return MIRGE_OK;
 }
 
@@ -911,6 +954,10 @@ int annotate(mirge_ctx* c) {
             return fail(c, MIRGE_E_ARG, "round " + std::to_string(r + 1) + " uses a library that is not loaded");
     }
     if (!c->libs[MIRGE_LIB_MIRNA].loaded) return fail(c, MIRGE_E_ARG, "mirna library not loaded");
+    for (int r = 0; r < c->n_rounds; ++r) {
+        const mirge_round& R = c->rounds[r];
+        if (std::min(R.seedmm, R.maxmm) == 1) { int rc = ensure_gapped(c, c->libs[R.lib]); if (rc) return rc; }
+    }
     kt_clear(c, "match"); kt_clear(c, "counts");
     // Round 1 walks the whole table and leaves every unique's annotation state behind (k_match_round<KW, 0>), so
     // ann_round / ann_ref / ann_amb need no fill of their own.

@@ -15,8 +15,10 @@ struct SimLib {
     std::vector<uint64_t> text, bad;
     std::vector<uint32_t> koff, ref_start, kbits, lut; int lut_shift = 5; std::vector<KEnt> kent; std::vector<uint64_t> kpre;
     uint32_t T; int kb;
+    std::vector<uint32_t> koffg, kbitsg; int kbg = 0; uint32_t gbk = 0;
     LibDev dev() const { LibDev L; L.text = text.data(); L.bad = bad.data(); L.koff = koff.data(); L.kent = kent.data(); L.kpre = kpre.data(); L.kbits = kbits.data();
-                         L.ref_start = ref_start.data(); L.ref_lut = lut.data(); L.lut_shift = lut_shift; L.n_refs = (uint32_t)ref_start.size() - 1; L.T = T; L.kb = kb; return L; }
+                         L.ref_start = ref_start.data(); L.ref_lut = lut.data(); L.lut_shift = lut_shift; L.n_refs = (uint32_t)ref_start.size() - 1; L.T = T; L.kb = kb;
+                         L.koffg = koffg.data(); L.kbitsg = kbg ? kbitsg.data() : nullptr; L.gbk = gbk; L.kbg = kbg; return L; }
 };
 
 extern "C" {
@@ -49,6 +51,22 @@ void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb)
     for (uint64_t b = 0; b < nb; ++b) S->koff[b + 1] += S->koff[b];
     std::vector<uint32_t> cur(S->koff.begin(), S->koff.end() - 1);
     for (uint32_t q = 0; q < T; ++q) S->kent[cur[text_kmer(S->text.data(), q, kb)]++] = make_kent(S->text.data(), q);
+    // gapped seed indexes, as ensure_gapped() in mirge_hip.hip lays them out (entries behind the contiguous index's)
+    if (kb >= 9 && T > 0) {
+        const int kbg = std::min(kb, 12); const uint64_t gbk = 1ull << (2 * kbg);
+        S->kent.resize(3 * (size_t)T, KEnt{0, 0, 0, 0});
+        S->koffg.assign(2 * (gbk + 1), 0); S->kbitsg.assign(2 * (gbk / 32), 0);
+        for (int g = 0; g < 2; ++g) {
+            uint32_t* ko = S->koffg.data() + (size_t)g * (gbk + 1);
+            std::vector<uint32_t> cnt(gbk + 1, 0);
+            for (uint32_t q = 0; q < T; ++q) cnt[index_bucket(S->text.data(), q, kbg, g + 1)]++;
+            uint32_t run = (uint32_t)((g + 1) * T);
+            for (uint64_t b = 0; b <= gbk; ++b) { ko[b] = run; if (b < gbk) { if (cnt[b]) S->kbitsg[(size_t)g * (gbk / 32) + (b >> 5)] |= 1u << (b & 31); run += cnt[b]; } }
+            std::vector<uint32_t> cur2(ko, ko + gbk);
+            for (uint32_t q = 0; q < T; ++q) S->kent[cur2[index_bucket(S->text.data(), q, kbg, g + 1)]++] = make_kent(S->text.data(), q);
+        }
+        S->kbg = kbg; S->gbk = (uint32_t)gbk;
+    }
     S->kpre.assign(S->kent.size(), 0);
     for (size_t i = 0; i < S->kent.size(); ++i) S->kpre[i] = make_kpre(S->kent[i]);
     return S;

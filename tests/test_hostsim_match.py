@@ -78,14 +78,17 @@ def _reads_from(rng, seqs, n, lo, hi, with_n=False):
 
 @pytest.mark.parametrize("seed,kb,with_n,lo,hi", [
     (1, 4, False, 16, 47), (2, 6, False, 16, 47), (3, 8, False, 16, 56), (4, 5, True, 16, 60),
-    (5, 7, True, 50, 124), (6, 4, False, 1, 20), (7, 10, False, 16, 47), (8, 3, True, 3, 30)])
+    (5, 7, True, 50, 124), (6, 4, False, 1, 20), (7, 10, False, 16, 47), (8, 3, True, 3, 30),
+    # kb >= 9: reads with 16..2*kb-1 seed nt go through the gapped seed indexes (kernels.h: gap_code)
+    (9, 12, False, 16, 30), (10, 11, True, 14, 40), (11, 9, False, 16, 24), (12, 12, True, 16, 26)])
 def test_match_one_equals_brute_force(hostsim, oracle, seed, kb, with_n, lo, hi):
     rng = np.random.default_rng(seed)
     seqs = _make_lib(rng, 24, 20, 140, with_n=with_n)
     sim = Sim(hostsim, seqs, kb)
     olib = OracleLib(seqs)
     reads = _reads_from(rng, seqs, 250, lo, hi, with_n=with_n)
-    extra_rounds = [(0, 0, 0, 2, 1, 10, 3, 3), (0, 0, 0, 0, 0, 5, 1, 1), (0, 0, 0, 0, 3, 28, 2, 0), (0, 0, 0, 0, 0, 12, 0, 3)]
+    extra_rounds = [(0, 0, 0, 2, 1, 10, 3, 3), (0, 0, 0, 0, 0, 5, 1, 1), (0, 0, 0, 0, 3, 28, 2, 0), (0, 0, 0, 0, 0, 12, 0, 3),
+                    (0, 0, 0, 0, 0, 20, 1, 1), (0, 0, 0, 0, 0, 28, 2, 1), (0, 0, 0, 1, 2, 28, 1, 2), (0, 0, 0, 0, 0, 17, 1, 3)]
     n_aligned = 0
     for rd in reads:
         for rnd in list(MIRGE_ROUNDS) + extra_rounds:
