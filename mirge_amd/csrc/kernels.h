@@ -36,14 +36,22 @@ struct LibDev {
     uint32_t n_refs;
     uint32_t T;                  // text length in nt, separators included
     int32_t  kb;
-    // gapped seed indexes (see gap_code): two more CSR indexes over every text position, bucket = kbg of the 12 nt that a
-    // 3-of-4-blocks shape selects from text[p, p+16).  Their entries live in kent / kpre behind the contiguous index's,
-    // so a candidate list is a range of the same arrays whichever index it came from.
-    const uint32_t* koffg;       // 2 x (gbk + 1) offsets into kent / kpre (absolute)
-    const uint32_t* kbitsg;      // 2 x gbk / 32 occupancy words
-    uint32_t gbk;                // buckets per gapped index = 4^kbg
-    int32_t  kbg;                // 0 = no gapped indexes
+    // Both-strand slot tables (nullable; built for the libraries whose koff does not stay cache-resident).  Every text
+    // position p is entered twice, as (p, fwd) under its k-mer and as (p, rev) under the reverse complement of its
+    // k-mer, so ONE bucket answers a piece for both strands; and the table is direct-addressed, one 16-byte slot per
+    // bucket: a bucket with one entry -- the usual non-empty case -- holds that entry itself.  An exact-bucket lookup
+    // is then the occupancy bit (cache-resident) + one random line, for both strands, instead of two dependent pairs
+    // koff -> kent.  Slot: pos = SLOT_EMPTY: nothing; pos = SLOT_LIST: c0 / c1 = the bucket's range in kent / kpre
+    // (entries of these tables sit behind the one-strand index's T entries); else the entry, bit 31 of pos = rev.
+    const KEnt*     kslot;       // 4^kb slots of the contiguous both-strand index
+    const uint32_t* kbits2;      // its occupancy bits (null: the slot is read without asking)
+    // gapped seed tables (see gap_code), both-strand as well: [0] serves read shape 1101, [1] read shape 1011
+    const KEnt*     kslotg;      // 2 x gbk slots (null: none)
+    const uint32_t* kbitsg;      // 2 x gbk / 32 occupancy words (nullable)
+    uint32_t gbk;                // buckets per gapped table = 4^kbg
+    int32_t  kbg;                // 0 = no gapped tables
 };
+constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu, SLOT_LIST = 0x7FFFFFFFu, POS_REV = 0x80000000u, POS_MASK = 0x7FFFFFFFu;
 
 struct RoundDev { int32_t lib, len_lt, len_gt, trim5, trim3, seedlen, seedmm, maxmm; };
 
@@ -290,25 +298,41 @@ MG_HD uint32_t text_kmer(const uint64_t* __restrict__ text, uint32_t p, int kb) 
     v &= ones(2 * kb);
     return (uint32_t)(rev2(v) >> (64 - 2 * kb));
 }
+// reverse complement of a k-nt code (first nt most significant)
+MG_HD uint32_t rc_code(uint32_t x, int k) { return (uint32_t)((~rev2((uint64_t)x)) >> (64 - 2 * k)) & (uint32_t)ones(2 * k); }
 // Gapped seeds.  A read whose seed is shorter than two index k-mers cannot be cut into two exact-lookup pieces: a
 // 16-nt seed against a kb = 12 index gives two 8-nt pieces, each a RANGE of 256 buckets (~55 candidates per lookup in
 // a 3.6 Mnt library).  Instead the first 16 seed nt are cut into four 4-nt blocks: with <= 1 mismatch among them three
 // blocks are exact, so the four shapes 1110, 0111, 1101, 1011 (1 = block used) between them find every such alignment,
-// each through ONE bucket of 12-nt specificity.  1110 and 0111 are contiguous 12-mers (the ordinary index at offsets 0
-// and 4); 1101 and 1011 are the two gapped indexes.  c16 = the 16-nt window as the TEXT holds it, first nt most
-// significant; g = 0: shape 1101, g = 1: shape 1011; the result is the 24-bit code of the 12 selected nt.
+// each through ONE bucket of 12-nt specificity.  1110 and 0111 are contiguous 12-mers (the contiguous table at offsets
+// 0 and 4); 1101 and 1011 are the two gapped tables.  c16 = a 16-nt window, first nt most significant; g = 0: shape
+// 1101, g = 1: shape 1011; the result is the 24-bit code of the 12 selected nt.
 MG_HD uint32_t gap_code(uint32_t c16, int g) {
     return g == 0 ? (((c16 >> 8) & 0xFFFF00u) | (c16 & 0xFFu)) : (((c16 >> 8) & 0xFF0000u) | (c16 & 0xFFFFu));
 }
-// bucket of text position p: shape 0 = the contiguous kb-mer, shape 1 / 2 = gapped index g = shape - 1 (k = kbg)
-MG_HD uint32_t index_bucket(const uint64_t* __restrict__ text, uint32_t p, int k, int shape) {
-    if (shape == 0) return text_kmer(text, p, k);
-    return gap_code(text_kmer(text, p, 16), shape - 1) >> (2 * (12 - k));
+// The two buckets of text position p in a both-strand table: bf holds (p, fwd), br holds (p, rev).
+//   shape 0: contiguous k-mer K          -> K, rc(K)
+//   shape 1: gapped table for READ shape 1101.  A forward alignment puts the read window on the text window W as it
+//            is: key = code1101(W).  A reverse alignment puts the reverse complement of the read window there, which
+//            mirrors the shape: the text's 1011 code is the reverse complement of the read's 1101 code, so
+//            key = rc(code1011(W)).
+//   shape 2: the same for read shape 1011 -> code1011(W), rc(code1101(W)).
+// Gapped keys are 12 nt; the bucket is their first k (= kbg) nt.
+MG_HD void both_buckets(const uint64_t* __restrict__ text, uint32_t p, int k, int shape, uint32_t& bf, uint32_t& br) {
+    if (shape == 0) { bf = text_kmer(text, p, k); br = rc_code(bf, k); return; }
+    const uint32_t c16 = text_kmer(text, p, 16);
+    const uint32_t a = gap_code(c16, shape - 1), b = gap_code(c16, 2 - shape);
+    bf = a >> (2 * (12 - k)); br = rc_code(b, 12) >> (2 * (12 - k));
 }
 __global__ void __launch_bounds__(256)
-k_kmer_hist(const uint64_t* __restrict__ text, uint32_t T, int kb, int shape, uint32_t* hist) {
+k_kmer_hist(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* hist) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < T) atomicAdd(&hist[index_bucket(text, p, kb, shape)], 1u);
+    if (p < T) atomicAdd(&hist[text_kmer(text, p, kb)], 1u);
+}
+__global__ void __launch_bounds__(256)
+k_both_hist(const uint64_t* __restrict__ text, uint32_t T, int k, int shape, uint32_t* hist) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < T) { uint32_t bf, br; both_buckets(text, p, k, shape, bf, br); atomicAdd(&hist[bf], 1u); atomicAdd(&hist[br], 1u); }
 }
 MG_HD KEnt make_kent(const uint64_t* __restrict__ text, uint32_t p) {
     // 96 bits of text starting at nt p - CTX_BACK (zeros for nt before the text starts)
@@ -332,13 +356,39 @@ MG_HD KEnt make_kent(const uint64_t* __restrict__ text, uint32_t p) {
 constexpr int PRE_SKIP = 4;
 MG_HD uint64_t make_kpre(const KEnt& e) { return ((((uint64_t)e.c0 | ((uint64_t)e.c1 << 32)) >> (2 * PRE_SKIP)) | ((uint64_t)e.c2 << (64 - 2 * PRE_SKIP))); }
 __global__ void __launch_bounds__(256)
-k_kmer_scatter(const uint64_t* __restrict__ text, uint32_t T, int kb, int shape, uint32_t* cursor, KEnt* kent, uint64_t* kpre) {
+k_kmer_scatter(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* cursor, KEnt* kent, uint64_t* kpre) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < T) {
         const KEnt e = make_kent(text, p);
-        const uint32_t at = atomicAdd(&cursor[index_bucket(text, p, kb, shape)], 1u);
+        const uint32_t at = atomicAdd(&cursor[text_kmer(text, p, kb)], 1u);
         kent[at] = e; kpre[at] = make_kpre(e);
     }
+}
+__global__ void __launch_bounds__(256)
+k_both_scatter(const uint64_t* __restrict__ text, uint32_t T, int k, int shape, uint32_t* cursor, KEnt* kent, uint64_t* kpre) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < T) {
+        KEnt e = make_kent(text, p);
+        const uint64_t pre = make_kpre(e);
+        uint32_t bf, br; both_buckets(text, p, k, shape, bf, br);
+        uint32_t at = atomicAdd(&cursor[bf], 1u);
+        kent[at] = e; kpre[at] = pre;
+        at = atomicAdd(&cursor[br], 1u);
+        e.pos = p | POS_REV;
+        kent[at] = e; kpre[at] = pre;
+    }
+}
+// slot table of one both-strand index from its CSR form (LibDev::kslot)
+__global__ void __launch_bounds__(256)
+k_slot_fill(const uint32_t* __restrict__ off, const KEnt* __restrict__ kent, uint64_t nb, KEnt* __restrict__ slot) {
+    uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint32_t lo = off[b], hi = off[b + 1];
+    KEnt e;
+    if (hi == lo) { e.pos = SLOT_EMPTY; e.c0 = 0; e.c1 = 0; e.c2 = 0; }
+    else if (hi == lo + 1) e = kent[lo];
+    else { e.pos = SLOT_LIST; e.c0 = lo; e.c1 = hi; e.c2 = 0; }
+    slot[b] = e;
 }
 
 // bucket occupancy bitmap from the histogram: most exact-length lookups of reads that do not belong to
@@ -683,72 +733,171 @@ MG_HD void koff_range(const LibDev& L, uint64_t b0, uint64_t b1, uint32_t& lo, u
     }
 }
 
-// Does this read go through the gapped seeds?  Only where two pieces would be range queries: a round of two pieces
-// (<= 1 mismatch guaranteed among the first 16 nt: they lie inside the seed, or the whole read holds <= 1), a seed of
-// >= 16 nt, pieces shorter than the index k-mer, and a library that carries the gapped indexes.
-template <int SW> MG_HD bool read_gapped(const LibDev& L, const RoundDev& P, const Query<SW>& Q) {
-    return L.kbg > 0 && round_np(P) == 2 && Q.ok && Q.s >= 16 && piece_cut(Q.span, 1, 2) < L.kb;
-}
-// lookups a read of this round makes at most (wave-uniform): four shapes where gapped reads can occur
-MG_HD int round_nlook(const LibDev& L, const RoundDev& P) { return (L.kbg > 0 && round_np(P) == 2) ? 4 : round_np(P); }
-// Shape 0 (blocks 0-2 exact) finds every alignment without a mismatch in the first 12 seed nt, so in particular every
-// alignment of stratum 0: once one is known the other shapes can only add worse strata.
+// Shape 0 of the gapped seeds (blocks 0-2 exact) finds every alignment without a mismatch in the first 12 seed nt, so
+// in particular every alignment of stratum 0: once one is known the other shapes can only add worse strata.
 MG_HD bool gap_needed(uint64_t score) { return score == 0 || 4 - (int)(score >> 36) >= 1; }
-// Lookup p of a prepared read on strand f -> candidate list [lo, hi) of kent / kpre and the position qs (oriented read)
-// of the window whose text position the entries carry.  Regular reads: piece p of np.  Gapped reads: p = 0 / 1 the
-// contiguous 12-mers at seed offsets 0 / 4 (ordinary index), p = 2 / 3 the gapped indexes 0 / 1.  On the reverse strand
-// the text holds the reverse complement of the 16-nt window, so its shape is mirrored (1101 <-> 1011): index g then
-// covers the OTHER read shape, and the two lookups p = 2, 3 still cover both.
-template <int SW, bool HASN>
-MG_HD void lookup_range(const Query<SW>& Q, const LibDev& L, bool gap, int np, int p, int f, int& qs, uint32_t& lo, uint32_t& hi) {
-    lo = 0; hi = 0; qs = 0;
-    if (gap && p >= 2) {
-        const int g = p - 2;
-        // the read blocks the shape selects must hold no N (bit i of the mask = read nt i; blocks 0,1,3 or 0,2,3)
-        if (HASN && ((uint32_t)Q.q[1].n[0] & (f != g ? 0xF0FFu : 0xFF0Fu))) return;
-        const uint32_t v = (uint32_t)Q.q[1].s[0];                      // first 16 nt of the forward read, nt 0 in the low bits
-        const uint32_t c16 = f ? (uint32_t)(rev2((uint64_t)v) >> 32) : ~v;
-        const uint32_t b = gap_code(c16, g) >> (2 * (12 - L.kbg));
-        qs = f ? 0 : Q.l - 16;
-        if (L.kbitsg && !((L.kbitsg[(uint32_t)g * (L.gbk >> 5) + (b >> 5)] >> (b & 31)) & 1)) return;
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
-        const u32x2 o = *reinterpret_cast<const u32x2*>(L.koffg + (size_t)g * (L.gbk + 1) + b);
-        lo = o.x; hi = o.y;
-        return;
+
+// ==========================================================================================
+// The probe path: rounds against a library that carries the both-strand slot tables (LibDev::kslot), 16-byte keys,
+// at most two seed pieces.  A read makes one lookup per piece -- occupancy bit, then the slot: ONE random line that
+// answers both strands and usually holds the candidate itself -- and the candidate is judged by shifting the
+// entry's 48-nt context into the read's coordinates (no per-piece layout of the read as in the generic matcher).
+// Lookups do not wait for each other: a wave's dependent memory steps are  key -> bits -> slots  for all pieces,
+// instead of  bits -> offsets -> entries  per piece and strand in turn.  Reads it cannot serve (a piece shorter than
+// the index k-mer, a bucket with more than PROBE_MAX_LIST entries, a full queue) are handed to the generic kernel.
+constexpr int PROBE_MAX_LIST = 16;
+
+MG_HD void shr128(uint64_t lo, uint64_t hi, int b, uint64_t& olo, uint64_t& ohi) {       // 0 <= b < 128
+    if (b >= 64) { olo = hi >> (b - 64); ohi = 0; }
+    else if (b) { olo = (lo >> b) | (hi << (64 - b)); ohi = hi >> b; }
+    else { olo = lo; ohi = hi; }
+}
+MG_HD void shl128(uint64_t lo, uint64_t hi, int b, uint64_t& olo, uint64_t& ohi) {       // 0 <= b < 128
+    if (b >= 64) { ohi = lo << (b - 64); olo = 0; }
+    else if (b) { ohi = (hi << b) | (lo >> (64 - b)); olo = lo << b; }
+    else { olo = lo; ohi = hi; }
+}
+// does the round / library pair run on the probe path (host-side dispatch; 16-byte key class only)
+MG_HD bool probe_round(const LibDev& L, const RoundDev& P) { return L.kslot != nullptr && round_np(P) <= 2; }
+// A read prepared for the probe path.
+struct ProbeRead {
+    uint64_t r[2], c[2];      // forward read / its reverse complement, 2-bit, nt 0 in the low bits
+    int l, s;                 // length after -5/-3, seed length
+    int np;                   // lookups through the contiguous table: pieces, or 2 for a gapped read
+    int ps[2];                // where their k-mers start in the forward read
+    bool gap;                 // the two gapped tables are asked as well
+    bool ok, served;          // ok: bowtie aligns the read at all; served: every lookup is an exact bucket
+};
+MG_HD void probe_setup(const uint64_t* key, const LibDev& L, const RoundDev& P, ProbeRead& R) {
+    Query<2> Q;
+    query_setup<2>(key, P, Q);
+    R.r[0] = Q.q[1].s[0]; R.r[1] = Q.q[1].s[1]; R.c[0] = Q.q[0].s[0]; R.c[1] = Q.q[0].s[1];
+    R.l = Q.l; R.s = Q.s; R.ok = Q.ok;
+    const int np = round_np(P);
+    const int cut = np == 2 ? piece_cut(Q.span, 1, 2) : Q.span;       // length of piece 0
+    // gapped (kernels.h: gap_code): two pieces that would both be range queries, >= 16 seed nt, tables present; the
+    // contiguous 12-mers at seed offsets 0 and 4 then take the place of the two pieces
+    R.gap = Q.ok && np == 2 && L.kslotg != nullptr && L.kbg > 0 && L.kb <= 12 && Q.s >= 16 && cut < L.kb;
+    R.np = R.gap ? 2 : np;
+    R.ps[0] = 0; R.ps[1] = R.gap ? 4 : cut;
+    R.served = Q.ok && (R.gap || (cut >= L.kb && (np == 1 || Q.span - cut >= L.kb)));
+}
+// lookup p (< R.np) in the contiguous table
+MG_HD uint32_t probe_bucket(const ProbeRead& R, const LibDev& L, int p, int& qsf, int& qsr) {
+    Oriented<2> o; o.s[0] = R.r[0]; o.s[1] = R.r[1]; o.n[0] = 0; o.l = R.l;
+    qsf = R.ps[p]; qsr = R.l - R.ps[p] - L.kb;
+    return kmer_code<2>(o, R.ps[p], L.kb);
+}
+// lookup in gapped table g (0: read shape 1101, 1: read shape 1011); the bucket index is relative to that table
+MG_HD uint32_t probe_bucket_gap(const ProbeRead& R, const LibDev& L, int g, int& qsf, int& qsr) {
+    const uint32_t c16 = (uint32_t)(rev2((uint64_t)(uint32_t)R.r[0]) >> 32);      // first 16 nt of the forward read, first nt most significant
+    qsf = 0; qsr = R.l - 16;
+    return gap_code(c16, g) >> (2 * (12 - L.kbg));
+}
+// One tagged entry against a read: 0 = no alignment, 1 = valid alignment (f, sm, tm, w set).  The entry's context
+// is text[pos - 16, pos + 32); the window starts qs nt before pos, so shifting the context by 16 - qs nt lines text
+// nt w + i up with read nt i.  What the context does not cover is read from the text (window_ok).
+MG_HD int probe_verify(const LibDev& L, const RoundDev& P, const ProbeRead& R, int qsf, int qsr, const KEnt& e,
+                       int& f, int& sm, int& tm, uint32_t& w) {
+    f = (e.pos >> 31) ? 0 : 1;
+    const uint32_t pos = e.pos & POS_MASK;
+    const int qs = f ? qsf : qsr, l = R.l;
+    if (pos < (uint32_t)qs) return 0;
+    w = pos - (uint32_t)qs;
+    if (w + (uint32_t)l > L.T) return 0;
+    const int off = CTX_BACK - qs;
+    const uint64_t c64 = (uint64_t)e.c0 | ((uint64_t)e.c1 << 32);
+    uint64_t x0, x1;
+    if (off >= 0) shr128(c64, (uint64_t)e.c2, 2 * off, x0, x1); else shl128(c64, (uint64_t)e.c2, -2 * off, x0, x1);
+    const int a = off < 0 ? -off : 0;
+    int b = CTX_NT - off; if (b > l) b = l;
+    const uint64_t q0 = f ? R.r[0] : R.c[0], q1 = f ? R.r[1] : R.c[1];
+    uint64_t d0 = 0, d1 = 0;
+    if (b > a) {
+        d0 = x0 ^ q0; d0 = (d0 | (d0 >> 1)) & M55 & (ones(2 * b) ^ ones(2 * a));
+        d1 = x1 ^ q1; d1 = (d1 | (d1 >> 1)) & M55 & (ones(2 * b - 64) ^ ones(2 * a - 64));
+        tm = popc64(d0) + popc64(d1);
+        if (tm > P.maxmm) return 0;
     }
-    int ps, pe;
-    if (gap) { ps = p ? 4 : 0; pe = p ? 16 : 12; }
-    else { if (p >= np) return; ps = piece_cut(Q.span, p, np); pe = piece_cut(Q.span, p + 1, np); }
-    uint64_t b0, b1;
-    if (piece_buckets_fwd<SW, HASN>(Q.q[1], Q.l, L.kb, f, ps, pe, qs, b0, b1)) koff_range(L, b0, b1, lo, hi);
+    uint64_t seedm[2];
+    range_mask<2>(f ? 0 : l - R.s, f ? R.s : l, seedm);
+    if (a == 0 && b == l) {
+        sm = popc64(d0 & seedm[0]) + popc64(d1 & seedm[1]);
+        if (sm > P.seedmm) return 0;
+        return window_clean<2>(L, (int64_t)w, l) ? 1 : 0;
+    }
+    Oriented<2> o; o.s[0] = q0; o.s[1] = q1; o.n[0] = 0; o.l = l;
+    const uint64_t nsp[2] = {0, 0};
+    return window_ok<2, false>(L, o, nsp, seedm, 0, 0, (int64_t)w, P, sm, tm) ? 1 : 0;
+}
+// slot -> 0 = empty, 1 = list [lo, hi), 2 = the entry itself
+MG_HD int slot_kind(const KEnt& e, uint32_t& lo, uint32_t& hi) {
+    if (e.pos == SLOT_EMPTY) return 0;
+    if (e.pos == SLOT_LIST) { lo = e.c0; hi = e.c1; return 1; }
+    return 2;
+}
+MG_HD KEnt load_slot(const KEnt* __restrict__ slots, uint64_t b) {
+    const uint4 v = *reinterpret_cast<const uint4*>(slots + b);
+    KEnt e; e.pos = v.x; e.c0 = v.y; e.c1 = v.z; e.c2 = v.w;
+    return e;
+}
+MG_HD bool bit_set(const uint32_t* __restrict__ bits, uint32_t b) { return !bits || ((bits[b >> 5] >> (b & 31)) & 1); }
+
+// Serial form of the probe path for one read: false = not served (ask the generic matcher).
+__host__ __device__ inline bool probe_one(const uint64_t* key, const LibDev& L, const RoundDev& P, uint64_t& score, uint64_t& kmax, uint64_t& kmin) {
+    ProbeRead R;
+    probe_setup(key, L, P, R);
+    score = 0; kmax = 0; kmin = 0;
+    if (!R.ok) return true;                      // bowtie skips the read: served, no alignment
+    if (!R.served) return false;
+    bool overflow = false;
+    auto take = [&](const KEnt* slots, const uint32_t* bits, uint32_t b, int qsf, int qsr) {
+        if (!bit_set(bits, b)) return;
+        const KEnt e = load_slot(slots, b);
+        uint32_t lo = 0, hi = 0;
+        const int kind = slot_kind(e, lo, hi);
+        if (kind == 0) return;
+        if (kind == 1 && hi - lo > (uint32_t)PROBE_MAX_LIST) { overflow = true; return; }
+        for (uint32_t c = lo; c < (kind == 2 ? lo + 1 : hi); ++c) {
+            int f, sm, tm; uint32_t w;
+            if (probe_verify(L, P, R, qsf, qsr, kind == 2 ? e : L.kent[c], f, sm, tm, w) == 1) {
+                uint64_t x = hit_score(sm, tm, w, f), y = hit_kmax(sm, w), z = hit_kmin(sm, w);
+                score = x > score ? x : score; kmax = y > kmax ? y : kmax; kmin = z > kmin ? z : kmin;
+            }
+        }
+    };
+    for (int p = 0; p < R.np; ++p) { int qsf, qsr; const uint32_t b = probe_bucket(R, L, p, qsf, qsr); take(L.kslot, L.kbits2, b, qsf, qsr); }
+    if (R.gap && gap_needed(score))
+        for (int g = 0; g < 2; ++g) {
+            int qsf, qsr; const uint32_t b = probe_bucket_gap(R, L, g, qsf, qsr);
+            take(L.kslotg + (size_t)g * L.gbk, L.kbitsg ? L.kbitsg + (size_t)g * (L.gbk >> 5) : nullptr, b, qsf, qsr);
+        }
+    return !overflow;
 }
 
 // Serial form of the matcher (one read, all candidates in turn): the definition the kernel below
 // parallelises, and what tests/hostsim runs on the CPU.
 template <int KW>
-__host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, const RoundDev& P, int32_t& ref, uint32_t& amb) {
+__host__ __device__ inline void match_generic(const uint64_t* key, const LibDev& L, const RoundDev& P, uint64_t& score, uint64_t& kmax, uint64_t& kmin) {
     constexpr int SW = KeyTraits<KW>::SW;
     constexpr bool HASN = KeyTraits<KW>::HASN;
+    score = 0; kmax = 0; kmin = 0;
     Query<SW> Q;
     query_setup<KW>(key, P, Q);
-    if (!Q.ok) return false;
+    if (!Q.ok) return;
     const int np = round_np(P);
-    const bool gap = read_gapped<SW>(L, P, Q);
-    const int nlook = gap ? 4 : np;
-    uint64_t score = 0, kmax = 0, kmin = 0;
-    for (int p = 0; p < nlook; ++p) {
-        if (p && !(gap ? gap_needed(score) : piece_needed(P, p, score))) break;    // as the kernel: decided once per lookup, before either strand
+    for (int p = 0; p < np; ++p) {
+        if (!piece_needed(P, p, score)) break;                  // as the kernel: decided once per piece, before either strand
         for (int fw = 1; fw >= 0; --fw) {
             const Oriented<SW>& o = Q.q[fw];
             Strand<SW, HASN> S;
             strand_setup<SW, HASN>(o, fw, Q.l, Q.s, P, S);
             if (!S.ok) continue;
-            int qs; uint32_t lo, hi;
-            lookup_range<SW, HASN>(Q, L, gap, np, p, fw, qs, lo, hi);
-            if (lo == hi) continue;
+            int qs; uint64_t b0, b1;
+            if (!piece_buckets_fwd<SW, HASN>(Q.q[1], Q.l, L.kb, fw, piece_cut(Q.span, p, np), piece_cut(Q.span, p + 1, np), qs, b0, b1)) continue;
             PieceAl A;
             piece_align<SW, HASN>(o, S, qs, fw, 0u, A);
-            A.lo = lo; A.hi = hi;
+            koff_range(L, b0, b1, A.lo, A.hi);
             const bool scan = A.hi - A.lo > 8;                  // as the kernel: long lists go through the pre-filter
             const PreAl R = pre_of(A);
             for (uint32_t c = A.lo; c < A.hi; ++c) {
@@ -763,6 +912,15 @@ __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, 
             }
         }
     }
+}
+// One read in one round, as the kernels decide it: the probe path where the library and the read allow it, else
+// the generic matcher.
+template <int KW>
+__host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, const RoundDev& P, int32_t& ref, uint32_t& amb) {
+    uint64_t score = 0, kmax = 0, kmin = 0;
+    bool done = false;
+    if (KW == 2 && probe_round(L, P)) done = probe_one(key, L, P, score, kmax, kmin);
+    if (!done) match_generic<KW>(key, L, P, score, kmax, kmin);
     if (!score) return false;
     ref = (int32_t)ref_of(L, (uint32_t)(score >> 1));
     amb = ref_of(L, (uint32_t)kmax) != ref_of(L, 0xFFFFFFFFu - (uint32_t)kmin);
@@ -886,17 +1044,16 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         sok[f] = Q.ok;       // (the N counts of a read and of its seed are the same on both strands)
         if (HASN) { Strand<SW, HASN> T; strand_setup<SW, HASN>(Q.q[1], 1, Q.l, Q.s, P, T); sok[f] = sok[f] && T.ok; }
     }
-    const bool gap = read_gapped<SW>(L, P, Q);
-    const int nlook = round_nlook(L, P);
-    for (int p = 0; p < nlook; ++p) {
+    for (int p = 0; p < np; ++p) {
+        const int ps = piece_cut(Q.span, p, np), pe = piece_cut(Q.span, p + 1, np);
         uint32_t lo[2], hi[2]; int qs[2];
         // what this thread checked itself is in s_best[tid] by now (queued lists are not: they can only add hits)
-        const bool need = p == 0 || (gap ? gap_needed(s_best[tid]) : (p < np && piece_needed(P, p, s_best[tid])));
-        if (p >= np && !__any(gap && need)) break;       // lookups 2, 3 exist for gapped reads only
+        const bool need = p == 0 || piece_needed(P, p, s_best[tid]);
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
+            uint64_t b0 = 0, b1 = 0;
             lo[f] = 0; hi[f] = 0; qs[f] = 0;
-            if (need && sok[f]) lookup_range<SW, HASN>(Q, L, gap, np, p, f, qs[f], lo[f], hi[f]);
+            if (need && sok[f] && piece_buckets_fwd<SW, HASN>(Q.q[1], Q.l, L.kb, f, ps, pe, qs[f], b0, b1)) koff_range(L, b0, b1, lo[f], hi[f]);
         }
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -1016,6 +1173,197 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         __syncthreads();
         if (surv) next_list[s_base + s_wcnt[tid >> 6] + (uint32_t)__popcll(sm_ & ((1ull << lane) - 1))] = u;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The probe path as a kernel (see probe_one for the serial form).  One thread per unique:
+//   1. key, eligibility, the read's two orientations, the buckets of its lookups;
+//   2. occupancy bits of all lookups, then the slots of all lookups with a set bit -- two dependent steps, every
+//      lane with several loads in flight;
+//   3. a slot that holds its bucket's only entry is judged on the spot (own results stay in registers); a bucket
+//      list of <= PROBE_MAX_LIST entries is queued in LDS in chunks of four entries;
+//   4. gapped reads that have no stratum-0 alignment yet repeat 2-3 on the two gapped tables;
+//   5. the block drains the queue, sixteen chunks per wave step (lane = chunk x entry), the owner's read coming
+//      from LDS; results meet the owners' through LDS atomic max;
+//   6. results, survivors -> next round's list, unserved reads -> the fallback list of the generic kernel.
+constexpr int PB = 256;                          // threads per block
+constexpr int PQCAP = 320;                       // queued chunks per block
+#ifndef MG_PROBE_WAVES
+#define MG_PROBE_WAVES 8
+#endif
+template <int RN, bool GAPR>
+__global__ void __launch_bounds__(PB, MG_PROBE_WAVES)
+k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb,
+              LibDev L, RoundDev P, unsigned long long* stats,
+              const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_n,
+              uint32_t* next_list, unsigned long long* next_n, uint32_t* fb_list, unsigned long long* fb_n) {
+    __shared__ unsigned long long s_best[3 * PB];
+    __shared__ uint64_t s_r0[PB], s_r1[PB];
+    __shared__ uint32_t s_ls[PB];                // l | s << 8
+    __shared__ uint32_t s_qlo[PQCAP], s_qmeta[PQCAP];       // chunk: first entry; owner (0-7) | entries (8-10) | qsf (11-17) | qsr (18-24)
+    __shared__ uint32_t s_qn, s_wcnt[2][PB / 64], s_base[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t n = list ? (uint32_t)*list_n : U;
+    if (blockIdx.x * PB >= n) return;
+    const uint32_t i = blockIdx.x * PB + tid;
+    const uint32_t u = i < n ? (list ? list[i] : i) : EMPTY;
+    uint64_t k[2] = {0, 0};
+    uint8_t done_before = 0;
+    if (u != EMPTY) {
+        if (RN == 0) { ann_round[u] = 0; ann_ref[u] = -1; ann_amb[u] = 0; }
+        else if (!list) done_before = ann_round[u];
+        k[0] = ukeys[(uint64_t)u * 2]; k[1] = ukeys[(uint64_t)u * 2 + 1];
+    }
+    const bool listed = u != EMPTY && done_before == 0;
+    bool active = false;
+    if (listed) {
+        const int len = key_len<2>(k);
+        active = !(P.len_lt && !(len < P.len_lt)) && !(P.len_gt && !(len > P.len_gt));
+    }
+    if (!__syncthreads_or(active) && !next_list) return;
+    s_best[tid] = 0; s_best[PB + tid] = 0; s_best[2 * PB + tid] = 0;
+    for (uint32_t j = tid; j < (uint32_t)PQCAP; j += PB) s_qmeta[j] = 0;
+    if (tid == 0) s_qn = 0;
+    if (!active) { k[0] = 0; k[1] = 0; }                       // an empty read: ok comes out false
+    ProbeRead R;
+    probe_setup(k, L, P, R);
+    R.ok = R.ok && active;
+    const bool run = R.ok && R.served;
+    bool fb = R.ok && !R.served;                                // -> the generic kernel
+    s_r0[tid] = R.r[0]; s_r1[tid] = R.r[1]; s_ls[tid] = (uint32_t)(R.l & 255) | ((uint32_t)(R.s & 255) << 8);
+    __syncthreads();
+
+    uint64_t score = 0, kmax = 0, kmin = 0;                     // what this thread finds itself
+    // a slot of one lookup: judge the single entry / queue the list
+    auto take = [&](const KEnt& e, int qsf, int qsr) {
+        uint32_t lo = 0, hi = 0;
+        const int kind = slot_kind(e, lo, hi);
+        if (kind == 2) {
+            int f, sm, tm; uint32_t w;
+            if (probe_verify(L, P, R, qsf, qsr, e, f, sm, tm, w) == 1) {
+                const uint64_t x = hit_score(sm, tm, w, f), y = hit_kmax(sm, w), z = hit_kmin(sm, w);
+                score = x > score ? x : score; kmax = y > kmax ? y : kmax; kmin = z > kmin ? z : kmin;
+            }
+        } else if (kind == 1) {
+            const uint32_t len = hi - lo;
+            if (len > (uint32_t)PROBE_MAX_LIST) { fb = true; return; }
+            const uint32_t nch = (len + 3) >> 2;
+            const uint32_t at = atomicAdd(&s_qn, nch);
+            if (at + nch > (uint32_t)PQCAP) { fb = true; return; }          // a full queue: chunks never written keep 0 entries
+            for (uint32_t c = 0; c < nch; ++c) {
+                const uint32_t cnt = len - 4 * c < 4 ? len - 4 * c : 4;
+                s_qlo[at + c] = lo + 4 * c;
+                s_qmeta[at + c] = tid | (cnt << 8) | ((uint32_t)qsf << 11) | ((uint32_t)qsr << 18);
+            }
+        }
+    };
+    {
+        uint32_t b[2]; int qsf[2], qsr[2]; bool have[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            have[p] = run && p < R.np;
+            b[p] = 0; qsf[p] = 0; qsr[p] = 0;
+            if (have[p]) b[p] = probe_bucket(R, L, p, qsf[p], qsr[p]);
+        }
+        if (L.kbits2) {
+            uint32_t wd[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) wd[p] = have[p] ? L.kbits2[b[p] >> 5] : 0u;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) have[p] = have[p] && ((wd[p] >> (b[p] & 31)) & 1);
+        }
+        KEnt e[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { e[p].pos = SLOT_EMPTY; e[p].c0 = 0; e[p].c1 = 0; e[p].c2 = 0; if (have[p]) e[p] = load_slot(L.kslot, b[p]); }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) if (have[p]) take(e[p], qsf[p], qsr[p]);
+    }
+    if (GAPR) {
+        const bool needg = run && R.gap && !fb && gap_needed(score);
+        if (__any(needg)) {
+            uint32_t b[2]; int qsf[2], qsr[2]; bool have[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) { have[g] = needg; b[g] = 0; qsf[g] = 0; qsr[g] = 0; if (needg) b[g] = probe_bucket_gap(R, L, g, qsf[g], qsr[g]); }
+            if (L.kbitsg) {
+                uint32_t wd[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) wd[g] = have[g] ? L.kbitsg[(uint32_t)g * (L.gbk >> 5) + (b[g] >> 5)] : 0u;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) have[g] = have[g] && ((wd[g] >> (b[g] & 31)) & 1);
+            }
+            KEnt e[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) { e[g].pos = SLOT_EMPTY; e[g].c0 = 0; e[g].c1 = 0; e[g].c2 = 0; if (have[g]) e[g] = load_slot(L.kslotg + (size_t)g * L.gbk, b[g]); }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) if (have[g]) take(e[g], qsf[g], qsr[g]);
+        }
+    }
+    __syncthreads();
+
+    // ---- drain: lane = (chunk, entry); every chunk's owner is told through LDS
+    {
+        const uint32_t qn = s_qn < (uint32_t)PQCAP ? s_qn : (uint32_t)PQCAP;
+        for (uint32_t base = (tid >> 6) * 16; base < qn; base += (PB / 64) * 16) {
+            const uint32_t j = base + (lane >> 2), ei = lane & 3;
+            const uint32_t meta = j < qn ? s_qmeta[j] : 0u;
+            if (ei < ((meta >> 8) & 7)) {
+                const uint32_t owner = meta & 255;
+                const KEnt e = L.kent[s_qlo[j] + ei];
+                ProbeRead O;
+                O.r[0] = s_r0[owner]; O.r[1] = s_r1[owner];
+                O.l = (int)(s_ls[owner] & 255); O.s = (int)((s_ls[owner] >> 8) & 255);
+                Oriented<2> fo, ro; fo.s[0] = O.r[0]; fo.s[1] = O.r[1]; fo.n[0] = 0; fo.l = O.l;
+                revcomp<2>(fo, ro);
+                O.c[0] = ro.s[0]; O.c[1] = ro.s[1];
+                int f, sm, tm; uint32_t w;
+                if (probe_verify(L, P, O, (int)((meta >> 11) & 127), (int)((meta >> 18) & 127), e, f, sm, tm, w) == 1) {
+                    atomicMax(&s_best[owner], (unsigned long long)hit_score(sm, tm, w, f));
+                    atomicMax(&s_best[PB + owner], (unsigned long long)hit_kmax(sm, w));
+                    atomicMax(&s_best[2 * PB + owner], (unsigned long long)hit_kmin(sm, w));
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- results
+    bool hit = false;
+    if (run && !fb) {
+        const unsigned long long a = s_best[tid], b2 = s_best[PB + tid], c2 = s_best[2 * PB + tid];
+        score = a > score ? a : score; kmax = b2 > kmax ? b2 : kmax; kmin = c2 > kmin ? c2 : kmin;
+        if (score) {
+            hit = true;
+            ann_round[u] = (uint8_t)(RN + 1);
+            const uint32_t r = ref_of(L, (uint32_t)(score >> 1));
+            ann_ref[u] = (int32_t)r;
+            const uint32_t pmax = (uint32_t)kmax, pmin = 0xFFFFFFFFu - (uint32_t)kmin;
+            const uint32_t r0 = L.ref_start[r], r1 = L.ref_start[r + 1];
+            bool amb = false;
+            if (pmin < r0 || pmax >= r1) amb = ref_of(L, pmax) != ref_of(L, pmin);
+            ann_amb[u] = (uint8_t)amb;
+        }
+    }
+    // unserved reads are counted (and listed as survivors, if they stay unaligned) by the generic kernel that takes them
+    const unsigned long long am = __ballot(active && !fb), hm = __ballot(hit);
+    if (lane == 0) {
+        const uint32_t slot = (blockIdx.x * 4 + (tid >> 6)) & (STAT_SLOTS - 1);
+        if (am) atomicAdd(&stats[(size_t)slot * 8], (unsigned long long)__popcll(am));
+        if (hm) atomicAdd(&stats[(size_t)(STAT_SLOTS + slot) * 8], (unsigned long long)__popcll(hm));
+    }
+    const bool surv = next_list != nullptr && listed && !hit && !fb;
+    const unsigned long long sv = __ballot(surv), fv = __ballot(fb);
+    if (lane == 0) { s_wcnt[0][tid >> 6] = (uint32_t)__popcll(sv); s_wcnt[1][tid >> 6] = (uint32_t)__popcll(fv); }
+    __syncthreads();
+    if (tid < 2) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < PB / 64; ++w) { const uint32_t c = s_wcnt[tid][w]; s_wcnt[tid][w] = tot; tot += c; }
+        s_base[tid] = tot ? (uint32_t)atomicAdd(tid ? fb_n : next_n, (unsigned long long)tot) : 0u;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1;
+    if (surv) next_list[s_base[0] + s_wcnt[0][tid >> 6] + (uint32_t)__popcll(sv & below)] = u;
+    if (fb) fb_list[s_base[1] + s_wcnt[1][tid >> 6] + (uint32_t)__popcll(fv & below)] = u;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -94,17 +94,20 @@ struct Lib {
     int kb = 0;
     DevBuf text, bad, koff, kent, kpre, kbits, dref, dlut; int lut_shift = 5;
     bool use_bits = true;                // false: koff is small enough to stay in L2, the occupancy bitmap is skipped
-    DevBuf koffg, kbitsg; int kbg = 0; uint32_t gbk = 0; bool use_bits_g = true;     // gapped seed indexes (built on first use: ensure_gapped)
+    // both-strand slot tables (LibDev::kslot ...): the contiguous one is built with the library when koff is too large to stay
+    // cache-resident, the two gapped ones the first time a cascade holds a round that can use them (ensure_gapped)
+    DevBuf kslot, kbits2, kslotg, kbitsg; bool has_both = false, use_bits2 = true, use_bits_g = true; int kbg = 0; uint32_t gbk = 0;
     LibDev dev() const {
         LibDev L;
         L.text = text.as<uint64_t>(); L.bad = bad.as<uint64_t>(); L.koff = koff.as<uint32_t>();
         L.kent = kent.as<KEnt>(); L.kpre = kpre.as<uint64_t>(); L.kbits = use_bits ? kbits.as<uint32_t>() : nullptr; L.ref_start = dref.as<uint32_t>();
         L.ref_lut = dlut.as<uint32_t>(); L.lut_shift = lut_shift;
         L.n_refs = (uint32_t)names.size(); L.T = (uint32_t)T; L.kb = kb;
-        L.koffg = koffg.as<uint32_t>(); L.kbitsg = (kbg && use_bits_g) ? kbitsg.as<uint32_t>() : nullptr; L.gbk = gbk; L.kbg = kbg;
+        L.kslot = has_both ? kslot.as<KEnt>() : nullptr; L.kbits2 = (has_both && use_bits2) ? kbits2.as<uint32_t>() : nullptr;
+        L.kslotg = kbg ? kslotg.as<KEnt>() : nullptr; L.kbitsg = (kbg && use_bits_g) ? kbitsg.as<uint32_t>() : nullptr; L.gbk = gbk; L.kbg = kbg;
         return L;
     }
-    void release() { text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); koffg.release(); kbitsg.release(); kbg = 0; loaded = false; }
+    void release() { text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); kslot.release(); kbits2.release(); kslotg.release(); kbitsg.release(); kbg = 0; has_both = false; loaded = false; }
 };
 
 constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
@@ -121,6 +124,7 @@ struct Class {
     DevBuf ann_round, ann_ref, ann_amb;
     DevBuf act[2];                              // ping-pong lists of still-unannotated uniques
     unsigned long long* act_n = nullptr;        // their lengths (device; lives in the context's state arena)
+    DevBuf fb; unsigned long long* fb_n = nullptr;      // reads the probe kernel hands to the generic kernel, per round (16-byte class)
     // The two classes run side by side (the 48-byte class is tiny: its kernels are latency-, not throughput-bound):
     // each has its own stream and its own collapse workspaces.
     hipStream_t st = nullptr;
@@ -129,7 +133,7 @@ struct Class {
     uint32_t pend_n = 0; int pend_sample = 0; bool pending = false;     // a collapse launched, not yet finished
     std::vector<Segment> segs;
     void reset() { U = 0; coo_n = 0; gvalid = false; segs.clear(); }
-    void release() { ukeys.release(); coo_g.release(); coo_c.release(); gslots.release(); act[0].release(); act[1].release(); ann_round.release(); ann_ref.release(); ann_amb.release();
+    void release() { ukeys.release(); coo_g.release(); coo_c.release(); gslots.release(); act[0].release(); act[1].release(); fb.release(); ann_round.release(); ann_ref.release(); ann_amb.release();
                      ws_lslots.release(); ws_cnt.release(); ws_cnt0.release(); ws_ctr.release(); }
 };
 
@@ -152,7 +156,7 @@ struct mirge_ctx {
     mirge_round rounds[MIRGE_MAX_ROUNDS];
     Class cls[2];                                   // [0] 16-byte keys, [1] 48-byte keys
     // workspaces
-    DevBuf ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist;
+    DevBuf ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist, off_tmp;
     DevBuf sh_ctr, sh_w[2];                         // multi-GPU exchange: per-owner / per-sample counters, weights of imported records
     int sh_world = 0; uint64_t sh_n[2][SHARD_MAX_WORLD] = {};
     DevBuf fq_raw, fq_seg, fq_segb, fq_start, fq_qstart, fq_qend;       // FASTQ ingest: raw file bytes, newline counts per segment (+ scanned), record starts
@@ -228,6 +232,72 @@ int scan_exclusive(mirge_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) 
     return MIRGE_OK;
 }
 
+// ---- both-strand slot tables (kernels.h: LibDev::kslot, both_buckets)
+__global__ void __launch_bounds__(256) k_add_u32(uint32_t* a, uint64_t n, uint32_t v) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += v;
+}
+bool want_slots() { const char* env = getenv("MIRGE_SLOTS"); return !(env && atoi(env) == 0); }      // A/B aid
+bool bits_wanted(uint64_t nbk) {                 // an occupancy bitmap in front of a slot table pays while it stays in the L2
+    uint64_t lim = 4ull << 20;
+    if (const char* env = getenv("MIRGE_BITS2_MAX")) lim = strtoull(env, nullptr, 10);
+    return nbk / 8 <= lim;
+}
+// One table: 2T entries (every position under its own key and under the reverse strand's) at entry offset `base` of
+// kent / kpre, which must have room; nbk = 4^k slots and nbk / 32 occupancy words into the given buffers.
+int build_both(mirge_ctx* c, Lib& L, int k, int shape, uint64_t base, KEnt* slots, uint32_t* bits) {
+    const uint64_t nbk = 1ull << (2 * k), T = L.T;
+    HIPCHK(c, c->hist.ensure((nbk + 1) * 4, false, 0, c->st));
+    HIPCHK(c, c->off_tmp.ensure((nbk + 1) * 4, false, 0, c->st));
+    HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (nbk + 1) * 4, c->st));
+    const uint32_t grid = (uint32_t)((T + 255) / 256);
+    hipLaunchKernelGGL(k_both_hist, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, k, shape, c->hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_bucket_bits, dim3((uint32_t)((nbk / 32 + 256) / 256)), dim3(256), 0, c->st, c->hist.as<uint32_t>(), nbk, bits);
+    int rc = scan_exclusive(c, c->hist.as<uint32_t>(), c->off_tmp.as<uint32_t>(), nbk + 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_add_u32, dim3((uint32_t)((nbk + 1 + 255) / 256)), dim3(256), 0, c->st, c->off_tmp.as<uint32_t>(), nbk + 1, (uint32_t)base);
+    HIPCHK(c, hipMemcpyAsync(c->hist.p, c->off_tmp.p, nbk * 4, hipMemcpyDeviceToDevice, c->st));
+    hipLaunchKernelGGL(k_both_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, k, shape, c->hist.as<uint32_t>(),
+                       L.kent.as<KEnt>(), L.kpre.as<uint64_t>());
+    hipLaunchKernelGGL(k_slot_fill, dim3((uint32_t)((nbk + 255) / 256)), dim3(256), 0, c->st, c->off_tmp.as<uint32_t>(), L.kent.as<KEnt>(), nbk, slots);
+    HIPCHK(c, hipGetLastError());
+    return MIRGE_OK;
+}
+// the contiguous table, with the library
+int build_contig_both(mirge_ctx* c, Lib& L) {
+    const uint64_t nbk = 1ull << (2 * L.kb), T = L.T;
+    if (T == 0 || 3 * T >= 0xFFFFFFF0ull) return MIRGE_OK;
+    HIPCHK(c, L.kent.ensure(3 * T * sizeof(KEnt), true, T * sizeof(KEnt), c->st));
+    HIPCHK(c, L.kpre.ensure(3 * T * 8, true, T * 8, c->st));
+    HIPCHK(c, L.kslot.ensure(nbk * sizeof(KEnt), false, 0, c->st));
+    HIPCHK(c, L.kbits2.ensure((nbk / 32 + 1) * 4, false, 0, c->st));
+    int rc = build_both(c, L, L.kb, 0, T, L.kslot.as<KEnt>(), L.kbits2.as<uint32_t>());
+    if (rc) return rc;
+    L.use_bits2 = bits_wanted(nbk);
+    L.has_both = true;
+    return MIRGE_OK;
+}
+// The two gapped tables (kernels.h: gap_code), built the first time a cascade holds a round that can use them -- a
+// two-piece round (<= 1 seed mismatch) against a library that has the contiguous table.
+int ensure_gapped(mirge_ctx* c, Lib& L) {
+    if (L.kbg || !L.loaded || !L.has_both || L.kb < 9 || L.T == 0 || 7 * L.T >= 0xFFFFFFF0ull) return MIRGE_OK;
+    if (const char* env = getenv("MIRGE_GAPPED")) { if (atoi(env) == 0) return MIRGE_OK; }      // A/B aid
+    const int kbg = std::min(L.kb, 12);
+    const uint64_t gbk = 1ull << (2 * kbg), T = L.T;
+    HIPCHK(c, L.kent.ensure(7 * T * sizeof(KEnt), true, 3 * T * sizeof(KEnt), c->st));
+    HIPCHK(c, L.kpre.ensure(7 * T * 8, true, 3 * T * 8, c->st));
+    HIPCHK(c, L.kslotg.ensure(2 * gbk * sizeof(KEnt), false, 0, c->st));
+    HIPCHK(c, L.kbitsg.ensure(2 * (gbk / 32) * 4 + 4, false, 0, c->st));
+    for (int g = 0; g < 2; ++g) {
+        int rc = build_both(c, L, kbg, g + 1, (3 + 2 * (uint64_t)g) * T, L.kslotg.as<KEnt>() + (size_t)g * gbk, L.kbitsg.as<uint32_t>() + (size_t)g * (gbk / 32));
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    L.use_bits_g = bits_wanted(gbk);
+    L.kbg = kbg; L.gbk = (uint32_t)gbk;
+    return MIRGE_OK;
+}
+
 // ---- library: host packing + device index build
 int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const char* seqs, const uint64_t* offs) {
     if (lib < 0 || lib >= MIRGE_N_LIBS) return fail(c, MIRGE_E_ARG, "library index out of range");
@@ -259,7 +329,7 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     for (auto& nm : L.names) { size_t e = nm.find_first_of(" \t"); L.short_names.push_back(e == std::string::npos ? nm : nm.substr(0, e)); }
     int kb = (int)std::lround(std::log2((double)std::max<uint64_t>(T, 16)) / 2.0) + 1;   // ~0.25 random entries per bucket
     L.kb = std::min(14, std::max(4, kb));
-    L.use_bits = true; L.kbg = 0; L.gbk = 0;
+    L.use_bits = true; L.kbg = 0; L.gbk = 0; L.has_both = false;
     if (const char* env = getenv("MIRGE_KB_BIAS")) L.kb = std::min(14, std::max(4, L.kb + atoi(env)));   // tuning aid
     if (const char* env = getenv("MIRGE_KB")) { if (atoi(env) >= 2 && atoi(env) <= 15) L.kb = atoi(env); }   // tests
     uint64_t nb = 1ull << (2 * L.kb);
@@ -288,60 +358,22 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (nb + 1) * 4, c->st));
     if (T > 0) {
         uint32_t grid = (uint32_t)((T + 255) / 256);
-        hipLaunchKernelGGL(k_kmer_hist, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, 0, c->hist.as<uint32_t>());
+        hipLaunchKernelGGL(k_kmer_hist, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, c->hist.as<uint32_t>());
         hipLaunchKernelGGL(k_bucket_bits, dim3((uint32_t)((nb / 32 + 256) / 256)), dim3(256), 0, c->st, c->hist.as<uint32_t>(), nb, L.kbits.as<uint32_t>());
         int rc = scan_exclusive(c, c->hist.as<uint32_t>(), L.koff.as<uint32_t>(), nb + 1);
         if (rc) return rc;
         HIPCHK(c, hipMemcpyAsync(c->hist.p, L.koff.p, nb * 4, hipMemcpyDeviceToDevice, c->st));
-        hipLaunchKernelGGL(k_kmer_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, 0, c->hist.as<uint32_t>(), L.kent.as<KEnt>(), L.kpre.as<uint64_t>());
+        hipLaunchKernelGGL(k_kmer_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, c->hist.as<uint32_t>(), L.kent.as<KEnt>(), L.kpre.as<uint64_t>());
         HIPCHK(c, hipGetLastError());
+        int min_kb = 11;                                              // koff of 4^11 + 1 words = 16 MB: not cache-resident any more
+        if (const char* env = getenv("MIRGE_SLOTS_MIN_KB")) min_kb = atoi(env);
+        if (L.kb >= min_kb && want_slots()) { rc = build_contig_both(c, L); if (rc) return rc; }
     } else {
         HIPCHK(c, hipMemsetAsync(L.koff.p, 0, (nb + 1) * 4, c->st));
     }
     HIPCHK(c, hipStreamSynchronize(c->st));
     L.loaded = true;
     c->annotated = false; c->counts_valid = false; c->host_valid = false;
-    return MIRGE_OK;
-}
-
-// The two gapped seed indexes of a library (kernels.h: gap_code), built the first time a cascade holds a round that
-// can use them -- a two-piece round (<= 1 seed mismatch) against a library whose index k-mer is longer than half a
-// 16-nt seed.  Their entries go behind the contiguous index's in kent / kpre.
-__global__ void __launch_bounds__(256) k_add_u32(uint32_t* a, uint64_t n, uint32_t v) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] += v;
-}
-int ensure_gapped(mirge_ctx* c, Lib& L) {
-    if (L.kbg || !L.loaded || L.kb < 9 || L.T == 0 || 3 * L.T >= 0xFFFFFFF0ull) return MIRGE_OK;
-    if (const char* env = getenv("MIRGE_GAPPED")) { if (atoi(env) == 0) return MIRGE_OK; }      // A/B aid
-    const int kbg = std::min(L.kb, 12);
-    const uint64_t gbk = 1ull << (2 * kbg), T = L.T;
-    HIPCHK(c, L.kent.ensure(3 * T * sizeof(KEnt), true, T * sizeof(KEnt), c->st));
-    HIPCHK(c, L.kpre.ensure(3 * T * 8, true, T * 8, c->st));
-    HIPCHK(c, L.koffg.ensure(2 * (gbk + 1) * 4, false, 0, c->st));
-    HIPCHK(c, L.kbitsg.ensure(2 * (gbk / 32) * 4 + 4, false, 0, c->st));
-    HIPCHK(c, c->hist.ensure((gbk + 1) * 4, false, 0, c->st));
-    HIPCHK(c, hipMemsetAsync(L.kbitsg.p, 0, 2 * (gbk / 32) * 4 + 4, c->st));
-    const uint32_t grid = (uint32_t)((T + 255) / 256);
-    for (int g = 0; g < 2; ++g) {
-        uint32_t* ko = L.koffg.as<uint32_t>() + (size_t)g * (gbk + 1);
-        HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (gbk + 1) * 4, c->st));
-        hipLaunchKernelGGL(k_kmer_hist, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, kbg, g + 1, c->hist.as<uint32_t>());
-        hipLaunchKernelGGL(k_bucket_bits, dim3((uint32_t)((gbk / 32 + 256) / 256)), dim3(256), 0, c->st, c->hist.as<uint32_t>(), gbk,
-                           L.kbitsg.as<uint32_t>() + (size_t)g * (gbk / 32));
-        int rc = scan_exclusive(c, c->hist.as<uint32_t>(), ko, gbk + 1);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_add_u32, dim3((uint32_t)((gbk + 1 + 255) / 256)), dim3(256), 0, c->st, ko, gbk + 1, (uint32_t)((g + 1) * T));
-        HIPCHK(c, hipMemcpyAsync(c->hist.p, ko, gbk * 4, hipMemcpyDeviceToDevice, c->st));
-        hipLaunchKernelGGL(k_kmer_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, kbg, g + 1, c->hist.as<uint32_t>(),
-                           L.kent.as<KEnt>(), L.kpre.as<uint64_t>());
-        HIPCHK(c, hipGetLastError());
-    }
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    uint64_t lim = 8ull << 20;
-    if (const char* env = getenv("MIRGE_BITS_ABOVE")) lim = strtoull(env, nullptr, 10);
-    L.use_bits_g = gbk * 4 > lim;
-    L.kbg = kbg; L.gbk = (uint32_t)gbk;
     return MIRGE_OK;
 }
 
@@ -895,12 +927,27 @@ int shard_import(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, u
 // ---- cascade + count vectors
 template <int KW, int RN>
 void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, int thr, int r) {
+    const uint32_t* list = r <= 1 ? (const uint32_t*)nullptr : C.act[(r + 1) & 1].as<uint32_t>();      // round 1 keeps no list: nearly everything survives it
+    uint32_t* next_list = (r >= 1 && r + 1 < c->n_rounds) ? C.act[r & 1].as<uint32_t>() : (uint32_t*)nullptr;
+    if (KW == 2 && probe_round(L, P)) {
+        // the probe path (kernels.h: k_probe_round) for what the slot tables can serve, then the generic kernel over the
+        // reads it handed on -- its grid covers the worst case, blocks beyond the list's length leave at once
+        const bool gapr = L.kslotg != nullptr && L.kbg > 0 && L.kb <= 12 && round_np(P) == 2;
+        auto kern = gapr ? k_probe_round<RN, true> : k_probe_round<RN, false>;
+        hipLaunchKernelGGL(kern, dim3((uint32_t)((C.U + PB - 1) / PB)), dim3(PB), 0, C.st,
+                           C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), C.ann_amb.as<uint8_t>(),
+                           L, P, c->d_stats + (size_t)r * STAT_WORDS, list, C.act_n + r, next_list, C.act_n + r + 1,
+                           C.fb.as<uint32_t>(), C.fb_n + r);
+        hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((C.U + MB - 1) / MB)), dim3(MB), 0, C.st,
+                           C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
+                           C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
+                           (const uint32_t*)C.fb.as<uint32_t>(), (const unsigned long long*)(C.fb_n + r), next_list, C.act_n + r + 1);
+        return;
+    }
     hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((C.U + MB - 1) / MB)), dim3(MB), 0, C.st,
                        C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
                        C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
-                       r <= 1 ? (const uint32_t*)nullptr : C.act[(r + 1) & 1].as<uint32_t>(), C.act_n + r,
-                       (r >= 1 && r + 1 < c->n_rounds) ? C.act[r & 1].as<uint32_t>() : (uint32_t*)nullptr,
-                       C.act_n + r + 1);   // round 1 keeps no list: nearly everything survives it
+                       list, C.act_n + r, next_list, C.act_n + r + 1);
 }
 
 // the round number is a template parameter only so that every round is its own kernel symbol in a
@@ -969,11 +1016,12 @@ int annotate(mirge_ctx* c) {
         HIPCHK(c, C.ann_amb.ensure(U, false, 0, c->st));
         HIPCHK(c, C.act[0].ensure(U * 4, false, 0, c->st));
         HIPCHK(c, C.act[1].ensure(U * 4, false, 0, c->st));
+        if (k == 0) HIPCHK(c, C.fb.ensure(U * 4, false, 0, c->st));
     }
     int M = (int)c->libs[MIRGE_LIB_MIRNA].names.size(), S = c->S;
     size_t qn = std::max<size_t>((size_t)M * S, 1);
     const size_t w_stats = MIRGE_MAX_ROUNDS * STAT_WORDS, w_cat = (size_t)5 * S, w_len = (size_t)128 * S, w_tu = (size_t)S;
-    const size_t w_out = w_stats + 2 * qn + w_cat + w_len + w_tu, w_all = w_out + 2 * (MIRGE_MAX_ROUNDS + 1);
+    const size_t w_out = w_stats + 2 * qn + w_cat + w_len + w_tu, w_all = w_out + 2 * (MIRGE_MAX_ROUNDS + 1) + MIRGE_MAX_ROUNDS;
     HIPCHK(c, c->state.ensure(w_all * 8, false, 0, c->st));
     if (c->h_state_cap < w_out) {
         if (c->h_state) (void)hipHostFree(c->h_state);
@@ -985,6 +1033,7 @@ int annotate(mirge_ctx* c) {
     c->d_quant = c->d_stats + w_stats; c->d_iscan = c->d_quant + qn; c->d_cat = c->d_iscan + qn;
     c->d_len = c->d_cat + w_cat; c->d_tu = c->d_len + w_len;
     c->cls[0].act_n = c->d_tu + w_tu; c->cls[1].act_n = c->cls[0].act_n + (MIRGE_MAX_ROUNDS + 1);
+    c->cls[0].fb_n = c->cls[1].act_n + (MIRGE_MAX_ROUNDS + 1);
     HIPCHK(c, hipMemsetAsync(c->state.p, 0, w_all * 8, c->st));
     hipEvent_t e0 = c->ev_t[0], e1 = c->ev_t[1], e2 = c->ev_t[2];
     HIPCHK(c, hipEventRecord(e0, c->st));
@@ -1167,7 +1216,7 @@ void mirge_close(mirge_ctx* c) {
     for (auto& L : c->libs) L.release();
     for (auto& C : c->cls) C.release();
     DevBuf* ws[] = {&c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
-                    &c->fq_raw, &c->fq_seg, &c->fq_segb, &c->fq_start, &c->fq_qstart, &c->fq_qend, &c->sh_ctr, &c->sh_w[0], &c->sh_w[1], &c->hist, &c->state};
+                    &c->fq_raw, &c->fq_seg, &c->fq_segb, &c->fq_start, &c->fq_qstart, &c->fq_qend, &c->sh_ctr, &c->sh_w[0], &c->sh_w[1], &c->hist, &c->off_tmp, &c->state};
     for (auto* b : ws) b->release();
     for (auto& k : c->kt) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);

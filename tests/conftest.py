@@ -32,7 +32,7 @@ def hostsim():
         subprocess.check_call(["hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, srcs[0]])
     L = C.CDLL(so)
     L.sim_lib_new.restype = C.c_void_p
-    L.sim_lib_new.argtypes = [C.c_int32, C.c_char_p, C.c_void_p, C.c_int32]
+    L.sim_lib_new.argtypes = [C.c_int32, C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
     L.sim_lib_free.argtypes = [C.c_void_p]
     L.sim_pack.argtypes = [C.c_char_p, C.c_int32, C.c_void_p]
     L.sim_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -1,0 +1,62 @@
+"""The probe path (kernels.h: k_probe_round -- both-strand slot tables, gapped seed tables, hand-over to the generic
+kernel) on the GPU against the CPU oracle.  The libraries of the other GPU tests are too small to get slot tables
+(they are built from kb = 11 up), so these cases force them onto small libraries and sweep the index k-mer length:
+kb = 9..12 with reads of 16..2*kb-1 seed nt exercises the gapped tables, kb = 6 the plain two-piece lookups, and
+reads shorter than a k-mer the hand-over."""
+import numpy as np
+import pytest
+
+from mirge_amd import capi, synth
+from tests import util
+from tests.test_gpu_parity import _compare_with_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kb,bits", [(6, "4194304"), (9, "4194304"), (10, "0"), (12, "4194304"), (12, "0")])
+def test_default_cascade_through_slot_tables(oracle, monkeypatch, kb, bits):
+    monkeypatch.setenv("MIRGE_SLOTS_MIN_KB", "4")
+    monkeypatch.setenv("MIRGE_KB", str(kb))
+    monkeypatch.setenv("MIRGE_BITS2_MAX", bits)           # 0: slots read without asking the occupancy bits
+    libs, _ = synth.make_libraries(synth.Profile.small(), 700 + kb)
+    samples = [synth.make_reads(libs, 50000, 710 + kb + s, zipf_perm_seed=5 + s) for s in range(2)]
+    seqs, lens = samples[0]
+    rng = np.random.default_rng(kb)
+    for i in rng.integers(0, len(lens), size=500):         # reads cut below a k-mer / a gapped window: the hand-over
+        lens[i] = int(rng.integers(1, 16))
+    res = _compare_with_oracle(oracle, libs, samples)
+    for r in range(1, 6):
+        assert (res["ann_round"] == r).sum() > 0, r
+
+
+@pytest.mark.parametrize("seed,kb", [(11, 7), (12, 10), (13, 12), (14, 11)])
+def test_random_cascades_through_slot_tables(oracle, monkeypatch, seed, kb):
+    """As test_gpu_parity.py::test_random_cascades_vs_oracle, with every library carrying slot tables: rounds of one or
+    two pieces run on the probe path, the others (and the 48-byte key class) on the generic kernel."""
+    monkeypatch.setenv("MIRGE_SLOTS_MIN_KB", "4")
+    monkeypatch.setenv("MIRGE_KB", str(kb))
+    rng = np.random.default_rng(2000 + seed)
+    libs, _ = synth.make_libraries(synth.Profile.small(), 400 + seed)
+    samples = [synth.make_reads(libs, 20000, 410 + seed)]
+    seqs, lens = samples[0]
+    for i in rng.integers(0, len(lens), size=300):
+        seqs[i, int(rng.integers(0, lens[i]))] = ord("N")
+    rounds = []
+    for _ in range(int(rng.integers(3, 9))):
+        len_lt = int(rng.choice([0, 0, 22, 26, 30])); len_gt = int(rng.choice([0, 0, 18, 25]))
+        rounds.append((int(rng.integers(0, 4)), len_lt, len_gt, int(rng.integers(0, 3)), int(rng.integers(0, 3)),
+                       int(rng.choice([12, 16, 20, 24, 28, 30])), int(rng.integers(0, 3)), int(rng.integers(0, 4))))
+    with capi.Context(None, 1, 0) as ctx:
+        util.load_libs_into(ctx, libs)
+        ctx.set_rounds(rounds)
+        ctx.collapse_seqs(seqs, 0, lens)
+        ctx.annotate()
+        got = util.gpu_result_dict(ctx)
+        cv = ctx.counts()
+        stats = [ctx.round_stats(r + 1)[:2] for r in range(len(rounds))]
+    res = oracle.run_path(util.oracle_libs(libs, oracle), samples, rounds=rounds, use_index=True, nthreads=8, maxlen=capi.MAX_READ_LEN)
+    assert got == util.oracle_result_dict(res), rounds
+    for k in ("quant", "iscan", "cat", "tuniq", "lenhist"):
+        assert np.array_equal(cv[k], res[k]), (k, rounds)
+    assert stats == [(int(a), int(b)) for a, b in res["stats"]][:len(rounds)], rounds
+    assert sum(b for _, b in stats) > 1000

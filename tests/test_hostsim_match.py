@@ -26,12 +26,12 @@ def _rc(s):
 
 
 class Sim:
-    def __init__(self, L, seqs, kb):
+    def __init__(self, L, seqs, kb, flags=0):
         self.L = L
         text = "".join(seqs).encode()
         offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
         np.cumsum([len(s) for s in seqs], out=offs[1:])
-        self.h = L.sim_lib_new(len(seqs), text, offs.ctypes.data, kb)
+        self.h = L.sim_lib_new(len(seqs), text, offs.ctypes.data, kb, flags)
 
     def match(self, read, rnd):
         key = np.zeros(6, dtype=np.uint64)
@@ -76,15 +76,17 @@ def _reads_from(rng, seqs, n, lo, hi, with_n=False):
     return out
 
 
+# flags: 0 = the one-strand CSR index only (small libraries), 1 = both-strand slot tables (+ gapped seed tables at
+# kb >= 9: reads with 16..2*kb-1 seed nt), 3 = the same without occupancy bits in front of the slots
+@pytest.mark.parametrize("flags", [0, 1, 3])
 @pytest.mark.parametrize("seed,kb,with_n,lo,hi", [
     (1, 4, False, 16, 47), (2, 6, False, 16, 47), (3, 8, False, 16, 56), (4, 5, True, 16, 60),
     (5, 7, True, 50, 124), (6, 4, False, 1, 20), (7, 10, False, 16, 47), (8, 3, True, 3, 30),
-    # kb >= 9: reads with 16..2*kb-1 seed nt go through the gapped seed indexes (kernels.h: gap_code)
     (9, 12, False, 16, 30), (10, 11, True, 14, 40), (11, 9, False, 16, 24), (12, 12, True, 16, 26)])
-def test_match_one_equals_brute_force(hostsim, oracle, seed, kb, with_n, lo, hi):
+def test_match_one_equals_brute_force(hostsim, oracle, seed, kb, with_n, lo, hi, flags):
     rng = np.random.default_rng(seed)
     seqs = _make_lib(rng, 24, 20, 140, with_n=with_n)
-    sim = Sim(hostsim, seqs, kb)
+    sim = Sim(hostsim, seqs, kb, flags)
     olib = OracleLib(seqs)
     reads = _reads_from(rng, seqs, 250, lo, hi, with_n=with_n)
     extra_rounds = [(0, 0, 0, 2, 1, 10, 3, 3), (0, 0, 0, 0, 0, 5, 1, 1), (0, 0, 0, 0, 3, 28, 2, 0), (0, 0, 0, 0, 0, 12, 0, 3),

@@ -92,7 +92,7 @@ def test_hostsim_policy(hostsim, oracle):
     text = "".join(lib).encode()
     offs = np.zeros(len(lib) + 1, dtype=np.uint64); np.cumsum([len(s) for s in lib], out=offs[1:])
     for kb in (3, 5, 8):
-        h = hostsim.sim_lib_new(len(lib), text, offs.ctypes.data, kb)
+        h = hostsim.sim_lib_new(len(lib), text, offs.ctypes.data, kb, kb & 1)
         for what, read, rnd, ref in cases:
             key = np.zeros(6, dtype=np.uint64)
             kw = hostsim.sim_pack(read.encode(), len(read), key.ctypes.data)
