@@ -23,6 +23,45 @@ constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 struct __attribute__((aligned(16))) KEnt { uint32_t pos, c0, c1, c2; };
 constexpr int CTX_BACK = 16, CTX_NT = 48;
 
+// Block schemes: seeds for reads too short to be cut into exact-lookup pieces.  The first 4B nt of the read are cut
+// into four blocks of B nt; with <= m mismatches among them at least 4 - m blocks are exact, so the C(4, m) shapes
+// that use 4 - m blocks (m = 1: 1110, 0111, 1101, 1011; m = 2: 1100, 1010, 1001, 0110, 0101, 0011) between them find
+// every such alignment, each through ONE bucket of (4 - m) * B nt of specificity.  A 16-nt seed with one mismatch
+// allowed thus makes four 12-nt lookups instead of two 8-nt range scans (~55 candidates each in a 3.6 Mnt library);
+// a 13-nt isomiR query with two mismatches allowed six 6-nt lookups instead of three 4-nt ones (~280 each in the
+// miRNA library).  One both-strand slot table per shape (TabDesc).
+// Entry of a both-strand table: 32 bytes that decide a candidate on their own -- position, reference, how far the
+// reference runs clean (no N, no boundary) to either side, and 96 nt of text around the window -- so that a lookup
+// touches ONE line and nothing else (no text, no N bitmap, no reference offsets; those cost ~5 more cache misses per
+// aligned read while entries carried 48 nt).
+//   pos  : text position of the looked-up window; bit 31 (POS_REV): the entry serves the reverse strand
+//   info : reference index (bits 0-19) | dl (20-25) | dr (26-31): how many nt the window may reach to the left of /
+//          from its lookup position on without meeting an N or a reference boundary (capped at 63: reads of the
+//          16-byte class are <= 56 nt)
+//   c    : 96 nt of text, 2-bit, laid out so that a read whose lookup starts ps nt into it lines up at context nt
+//          40 - ps: text[pos - 40, pos + 56) for a forward entry.
+// A reverse entry is stored MIRRORED: its context is the reverse complement of text[pos + K - 56, pos + K + 40)
+// (K = length of the looked-up window: the k-mer, or a scheme's 4B) and dl / dr are measured in that orientation,
+// so that the FORWARD read is compared against it exactly as against a forward entry -- the matcher never builds a
+// reverse complement, and the strand only shows in the reported position.
+struct __attribute__((aligned(32))) PEnt { uint32_t pos, info, c[6]; };
+constexpr int PCTX_NT = 96, PCTX_BACK = 40;
+constexpr uint32_t PENT_MAX_REFS = 1u << 20;
+// A table (the contiguous one or one scheme's shape tables) inside the library's slot / occupancy buffers.
+struct TabDesc {
+    uint32_t slot_off;           // first slot (LibDev::slots); a scheme's shape i starts nbk * i further on
+    uint32_t bits_off;           // first occupancy word (LibDev::sbits); shape i starts nbk / 32 * i further on
+    uint32_t info;               // kbs (0-7) | B (8-15; 0 = contiguous) | m (16-23) | occupancy bits in use (24)
+};
+MG_HD int tab_kbs(const TabDesc& t) { return (int)(t.info & 255); }
+MG_HD int tab_B(const TabDesc& t) { return (int)((t.info >> 8) & 255); }
+MG_HD int tab_m(const TabDesc& t) { return (int)((t.info >> 16) & 255); }
+MG_HD bool tab_bits(const TabDesc& t) { return (t.info >> 24) & 1; }
+MG_HD uint32_t tab_info(int kbs, int B, int m, bool bits) { return (uint32_t)kbs | ((uint32_t)B << 8) | ((uint32_t)m << 16) | ((uint32_t)bits << 24); }
+constexpr int MAX_SCHEMES = 6;                   // per library
+constexpr int ROUND_SCHEMES = 3;                 // per round
+// the schemes one round may use, most specific first (round_schemes)
+struct RoundSch { int32_t n; TabDesc t[ROUND_SCHEMES]; };
 struct LibDev {
     const uint64_t* text;
     const uint64_t* bad;
@@ -36,20 +75,19 @@ struct LibDev {
     uint32_t n_refs;
     uint32_t T;                  // text length in nt, separators included
     int32_t  kb;
-    // Both-strand slot tables (nullable; built for the libraries whose koff does not stay cache-resident).  Every text
-    // position p is entered twice, as (p, fwd) under its k-mer and as (p, rev) under the reverse complement of its
-    // k-mer, so ONE bucket answers a piece for both strands; and the table is direct-addressed, one 16-byte slot per
-    // bucket: a bucket with one entry -- the usual non-empty case -- holds that entry itself.  An exact-bucket lookup
-    // is then the occupancy bit (cache-resident) + one random line, for both strands, instead of two dependent pairs
-    // koff -> kent.  Slot: pos = SLOT_EMPTY: nothing; pos = SLOT_LIST: c0 / c1 = the bucket's range in kent / kpre
-    // (entries of these tables sit behind the one-strand index's T entries); else the entry, bit 31 of pos = rev.
-    const KEnt*     kslot;       // 4^kb slots of the contiguous both-strand index
-    const uint32_t* kbits2;      // its occupancy bits (null: the slot is read without asking)
-    // gapped seed tables (see gap_code), both-strand as well: [0] serves read shape 1101, [1] read shape 1011
-    const KEnt*     kslotg;      // 2 x gbk slots (null: none)
-    const uint32_t* kbitsg;      // 2 x gbk / 32 occupancy words (nullable)
-    uint32_t gbk;                // buckets per gapped table = 4^kbg
-    int32_t  kbg;                // 0 = no gapped tables
+    // Both-strand slot tables (slots == null: none).  Every text position p is entered twice, as (p, fwd) under its
+    // k-mer and as (p, rev) under the reverse complement of its k-mer, so ONE bucket answers a piece for both strands;
+    // and a table is direct-addressed, one 32-byte slot per bucket: a bucket with one entry -- the usual non-empty
+    // case -- holds that entry itself (PEnt).  An exact-bucket lookup is then the occupancy bit (cache-resident) + one
+    // random line, for both strands, instead of two dependent pairs koff -> kent and the text behind them.
+    // Slot: pos = SLOT_EMPTY: nothing; pos = SLOT_LIST: info / c[0] = the bucket's range in `pent`; else the entry.
+    // All tables of a library share these buffers.
+    const PEnt*     slots;
+    const uint32_t* sbits;
+    const PEnt*     pent;        // entries of the buckets that hold more than one
+    TabDesc   ctab;              // the contiguous table: 4^kb slots
+    int32_t   nsch;
+    TabDesc   sch[MAX_SCHEMES];  // the block schemes built so far
 };
 constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu, SLOT_LIST = 0x7FFFFFFFu, POS_REV = 0x80000000u, POS_MASK = 0x7FFFFFFFu;
 
@@ -300,29 +338,40 @@ MG_HD uint32_t text_kmer(const uint64_t* __restrict__ text, uint32_t p, int kb) 
 }
 // reverse complement of a k-nt code (first nt most significant)
 MG_HD uint32_t rc_code(uint32_t x, int k) { return (uint32_t)((~rev2((uint64_t)x)) >> (64 - 2 * k)) & (uint32_t)ones(2 * k); }
-// Gapped seeds.  A read whose seed is shorter than two index k-mers cannot be cut into two exact-lookup pieces: a
-// 16-nt seed against a kb = 12 index gives two 8-nt pieces, each a RANGE of 256 buckets (~55 candidates per lookup in
-// a 3.6 Mnt library).  Instead the first 16 seed nt are cut into four 4-nt blocks: with <= 1 mismatch among them three
-// blocks are exact, so the four shapes 1110, 0111, 1101, 1011 (1 = block used) between them find every such alignment,
-// each through ONE bucket of 12-nt specificity.  1110 and 0111 are contiguous 12-mers (the contiguous table at offsets
-// 0 and 4); 1101 and 1011 are the two gapped tables.  c16 = a 16-nt window, first nt most significant; g = 0: shape
-// 1101, g = 1: shape 1011; the result is the 24-bit code of the 12 selected nt.
-MG_HD uint32_t gap_code(uint32_t c16, int g) {
-    return g == 0 ? (((c16 >> 8) & 0xFFFF00u) | (c16 & 0xFFu)) : (((c16 >> 8) & 0xFF0000u) | (c16 & 0xFFFFu));
+// ---- block schemes: shapes and codes
+MG_HD int scheme_nshapes(int m) { return m == 1 ? 4 : 6; }
+// shape i of the scheme as a block mask, bit j = block j (block 0 = the first B nt).  Shape 0 is the one made of the
+// leading blocks: it finds every alignment without a mismatch in the first (4 - m) * B nt.
+MG_HD uint32_t scheme_shape(int m, int i) { return ((m == 1 ? 0xDBE7u : 0xCA6953u) >> (4 * i)) & 15u; }
+MG_HD uint32_t shape_mirror(uint32_t mask) { return ((mask & 1) << 3) | ((mask & 2) << 1) | ((mask & 4) >> 1) | ((mask & 8) >> 3); }
+// code of the blocks a shape selects from a 4B-nt window (first nt most significant), in window order
+MG_HD uint32_t shape_code(uint64_t win, int B, uint32_t mask) {
+    uint32_t code = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((mask >> j) & 1) code = (code << (2 * B)) | (uint32_t)((win >> (2 * B * (3 - j))) & ones(2 * B));
+    return code;
+}
+// up to 32 nt of text starting at p, first nt most significant
+MG_HD uint64_t text_window(const uint64_t* __restrict__ text, uint32_t p, int k) {
+    uint32_t wi = p >> 5; int bs = (p & 31) * 2;
+    uint64_t t0 = text[wi], t1 = text[wi + 1];
+    uint64_t v = bs ? (t0 >> bs) | (t1 << (64 - bs)) : t0;
+    v &= ones(2 * k);
+    return rev2(v) >> (64 - 2 * k);
 }
 // The two buckets of text position p in a both-strand table: bf holds (p, fwd), br holds (p, rev).
-//   shape 0: contiguous k-mer K          -> K, rc(K)
-//   shape 1: gapped table for READ shape 1101.  A forward alignment puts the read window on the text window W as it
-//            is: key = code1101(W).  A reverse alignment puts the reverse complement of the read window there, which
-//            mirrors the shape: the text's 1011 code is the reverse complement of the read's 1101 code, so
-//            key = rc(code1011(W)).
-//   shape 2: the same for read shape 1011 -> code1011(W), rc(code1101(W)).
-// Gapped keys are 12 nt; the bucket is their first k (= kbg) nt.
-MG_HD void both_buckets(const uint64_t* __restrict__ text, uint32_t p, int k, int shape, uint32_t& bf, uint32_t& br) {
-    if (shape == 0) { bf = text_kmer(text, p, k); br = rc_code(bf, k); return; }
-    const uint32_t c16 = text_kmer(text, p, 16);
-    const uint32_t a = gap_code(c16, shape - 1), b = gap_code(c16, 2 - shape);
-    bf = a >> (2 * (12 - k)); br = rc_code(b, 12) >> (2 * (12 - k));
+//   contiguous table (B = 0): k-mer K -> K, rc(K).
+//   shape table: a forward alignment puts the read window on the text window W as it is: key = code of the shape's
+//   blocks in W.  A reverse alignment puts the reverse complement of the read window there, which mirrors the block
+//   order: the read's code is then the reverse complement of W's code under the MIRRORED shape.
+// k = nt of the key that index the table (its leading nt); sel = nt the shape selects.
+MG_HD void both_buckets(const uint64_t* __restrict__ text, uint32_t p, int k, int B, uint32_t mask, uint32_t& bf, uint32_t& br) {
+    if (B == 0) { bf = text_kmer(text, p, k); br = rc_code(bf, k); return; }
+    const uint64_t win = text_window(text, p, 4 * B);
+    const int sel = B * __builtin_popcount(mask);
+    bf = shape_code(win, B, mask) >> (2 * (sel - k));
+    br = rc_code(shape_code(win, B, shape_mirror(mask)), sel) >> (2 * (sel - k));
 }
 __global__ void __launch_bounds__(256)
 k_kmer_hist(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* hist) {
@@ -330,9 +379,9 @@ k_kmer_hist(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* his
     if (p < T) atomicAdd(&hist[text_kmer(text, p, kb)], 1u);
 }
 __global__ void __launch_bounds__(256)
-k_both_hist(const uint64_t* __restrict__ text, uint32_t T, int k, int shape, uint32_t* hist) {
+k_both_hist(const uint64_t* __restrict__ text, uint32_t T, int k, int B, uint32_t mask, uint32_t* hist) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < T) { uint32_t bf, br; both_buckets(text, p, k, shape, bf, br); atomicAdd(&hist[bf], 1u); atomicAdd(&hist[br], 1u); }
+    if (p < T) { uint32_t bf, br; both_buckets(text, p, k, B, mask, bf, br); atomicAdd(&hist[bf], 1u); atomicAdd(&hist[br], 1u); }
 }
 MG_HD KEnt make_kent(const uint64_t* __restrict__ text, uint32_t p) {
     // 96 bits of text starting at nt p - CTX_BACK (zeros for nt before the text starts)
@@ -364,30 +413,82 @@ k_kmer_scatter(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* 
         kent[at] = e; kpre[at] = make_kpre(e);
     }
 }
+// 64 bits of 2-bit text starting at nt position x (may be negative: nt before the text read as zeros)
+MG_HD uint64_t text_bits64(const uint64_t* __restrict__ text, int64_t x) {
+    // branch-free on purpose (see make_kent)
+    const uint64_t st = x < 0 ? 0ull : (uint64_t)x;
+    const int sh = x < 0 ? (x < -32 ? 64 : (int)(-x) * 2) : 0;
+    const uint64_t wi = st >> 5; const int bs = (int)(st & 31) * 2;
+    const uint64_t t0 = text[wi], t1 = text[wi + 1];
+    const uint64_t v = bs ? (t0 >> bs) | (t1 << (64 - bs)) : t0;
+    return sh >= 64 ? 0ull : v << sh;
+}
+// 64 bits of the N / boundary bitmap for positions x .. x + 63 (positions before the text count as set)
+MG_HD uint64_t bad_bits64(const uint64_t* __restrict__ bad, int64_t x) {
+    const uint64_t st = x < 0 ? 0ull : (uint64_t)x;
+    const int sh = x < 0 ? (x < -64 ? 64 : (int)(-x)) : 0;
+    const uint64_t wi = st >> 6; const int bs = (int)(st & 63);
+    const uint64_t b0 = bad[wi], b1 = bad[wi + 1];
+    const uint64_t v = bs ? (b0 >> bs) | (b1 << (64 - bs)) : b0;
+    return sh >= 64 ? ~0ull : (sh ? (v << sh) | ones(sh) : v);
+}
+MG_HD uint32_t ref_of(const LibDev& L, uint32_t pos);
+// K = length of the window the table looks up (k-mer, or 4B of a scheme)
+MG_HD PEnt make_pent(const LibDev& L, uint32_t p, int K, bool rev) {
+    PEnt e;
+    e.pos = p | (rev ? POS_REV : 0u);
+    const uint64_t right = bad_bits64(L.bad, (int64_t)p), left = bad_bits64(L.bad, (int64_t)p - 64);
+    int dr = right ? __builtin_ctzll(right) : 64, dl = left ? __builtin_clzll(left) : 64;       // clean nt from p on / just before p
+    if (rev) {
+        // mirrored: "left" of the lookup position is what lies beyond the window's end in the text, and the other way round
+        const int ml = dr - K, mr = dl + K;
+        dl = ml < 0 ? 0 : ml; dr = ml < 0 ? 0 : mr;            // ml < 0: the looked-up window itself is not clean
+    }
+    dr = dr > 63 ? 63 : dr; dl = dl > 63 ? 63 : dl;
+    e.info = ref_of(L, p) | ((uint32_t)dl << 20) | ((uint32_t)dr << 26);
+    if (!rev) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint64_t v = text_bits64(L.text, (int64_t)p - PCTX_BACK + 32 * j);
+            e.c[2 * j] = (uint32_t)v; e.c[2 * j + 1] = (uint32_t)(v >> 32);
+        }
+    } else {
+        // reverse complement of text[cs, cs + 96), cs = p + K - 56: word j of the result = ~rev2(word 2 - j)
+        const int64_t cs = (int64_t)p + K - (PCTX_NT - PCTX_BACK);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint64_t v = ~rev2(text_bits64(L.text, cs + 32 * (2 - j)));
+            e.c[2 * j] = (uint32_t)v; e.c[2 * j + 1] = (uint32_t)(v >> 32);
+        }
+    }
+    return e;
+}
 __global__ void __launch_bounds__(256)
-k_both_scatter(const uint64_t* __restrict__ text, uint32_t T, int k, int shape, uint32_t* cursor, KEnt* kent, uint64_t* kpre) {
+k_both_scatter(LibDev L, int k, int B, uint32_t mask, uint32_t* cursor, PEnt* pent) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < T) {
-        KEnt e = make_kent(text, p);
-        const uint64_t pre = make_kpre(e);
-        uint32_t bf, br; both_buckets(text, p, k, shape, bf, br);
+    if (p < L.T) {
+        const int K = B ? 4 * B : k;
+        uint32_t bf, br; both_buckets(L.text, p, k, B, mask, bf, br);
         uint32_t at = atomicAdd(&cursor[bf], 1u);
-        kent[at] = e; kpre[at] = pre;
+        pent[at] = make_pent(L, p, K, false);
         at = atomicAdd(&cursor[br], 1u);
-        e.pos = p | POS_REV;
-        kent[at] = e; kpre[at] = pre;
+        pent[at] = make_pent(L, p, K, true);
     }
 }
-// slot table of one both-strand index from its CSR form (LibDev::kslot)
+// slot table of one both-strand index from its CSR form (LibDev::slots)
 __global__ void __launch_bounds__(256)
-k_slot_fill(const uint32_t* __restrict__ off, const KEnt* __restrict__ kent, uint64_t nb, KEnt* __restrict__ slot) {
+k_slot_fill(const uint32_t* __restrict__ off, const PEnt* __restrict__ pent, uint64_t nb, PEnt* __restrict__ slot) {
     uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const uint32_t lo = off[b], hi = off[b + 1];
-    KEnt e;
-    if (hi == lo) { e.pos = SLOT_EMPTY; e.c0 = 0; e.c1 = 0; e.c2 = 0; }
-    else if (hi == lo + 1) e = kent[lo];
-    else { e.pos = SLOT_LIST; e.c0 = lo; e.c1 = hi; e.c2 = 0; }
+    PEnt e;
+    if (hi == lo + 1) e = pent[lo];
+    else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) e.c[j] = 0;
+        if (hi == lo) { e.pos = SLOT_EMPTY; e.info = 0; }
+        else { e.pos = SLOT_LIST; e.info = lo; e.c[0] = hi; }
+    }
     slot[b] = e;
 }
 
@@ -733,146 +834,186 @@ MG_HD void koff_range(const LibDev& L, uint64_t b0, uint64_t b1, uint32_t& lo, u
     }
 }
 
-// Shape 0 of the gapped seeds (blocks 0-2 exact) finds every alignment without a mismatch in the first 12 seed nt, so
-// in particular every alignment of stratum 0: once one is known the other shapes can only add worse strata.
-MG_HD bool gap_needed(uint64_t score) { return score == 0 || 4 - (int)(score >> 36) >= 1; }
-
 // ==========================================================================================
-// The probe path: rounds against a library that carries the both-strand slot tables (LibDev::kslot), 16-byte keys,
-// at most two seed pieces.  A read makes one lookup per piece -- occupancy bit, then the slot: ONE random line that
-// answers both strands and usually holds the candidate itself -- and the candidate is judged by shifting the
-// entry's 48-nt context into the read's coordinates (no per-piece layout of the read as in the generic matcher).
-// Lookups do not wait for each other: a wave's dependent memory steps are  key -> bits -> slots  for all pieces,
-// instead of  bits -> offsets -> entries  per piece and strand in turn.  Reads it cannot serve (a piece shorter than
-// the index k-mer, a bucket with more than PROBE_MAX_LIST entries, a full queue) are handed to the generic kernel.
-constexpr int PROBE_MAX_LIST = 16;
+// The probe path: rounds against a library that carries the both-strand slot tables (LibDev::slots), 16-byte keys,
+// at most three seed pieces.  A read makes one lookup per piece -- occupancy bit, then the slot: ONE random line
+// that answers both strands and usually holds the candidate itself, self-contained (PEnt) -- and the candidate is
+// judged by shifting the entry's context into the read's coordinates (no per-piece layout of the read as in the
+// generic matcher).  Lookups do not wait for each other: a wave's dependent memory steps are  key -> bits -> slots
+// for two lookups at a time, instead of  bits -> offsets -> entries -> text  per piece and strand in turn.  A read
+// whose pieces are shorter than the index k-mer goes through a block scheme if the library carries one that fits.
+// Reads the path cannot serve (no fitting scheme, a bucket with more than PROBE_MAX_LIST entries, a full queue) are
+// handed to the generic kernel.
+constexpr int PROBE_MAX_LIST = 4096;
 
-MG_HD void shr128(uint64_t lo, uint64_t hi, int b, uint64_t& olo, uint64_t& ohi) {       // 0 <= b < 128
-    if (b >= 64) { olo = hi >> (b - 64); ohi = 0; }
-    else if (b) { olo = (lo >> b) | (hi << (64 - b)); ohi = hi >> b; }
-    else { olo = lo; ohi = hi; }
-}
-MG_HD void shl128(uint64_t lo, uint64_t hi, int b, uint64_t& olo, uint64_t& ohi) {       // 0 <= b < 128
-    if (b >= 64) { ohi = lo << (b - 64); olo = 0; }
-    else if (b) { ohi = (hi << b) | (lo >> (64 - b)); olo = lo << b; }
-    else { olo = lo; ohi = hi; }
-}
 // does the round / library pair run on the probe path (host-side dispatch; 16-byte key class only)
-MG_HD bool probe_round(const LibDev& L, const RoundDev& P) { return L.kslot != nullptr && round_np(P) <= 2; }
+MG_HD bool probe_round(const LibDev& L, const RoundDev& P) { return L.slots != nullptr && round_np(P) <= 3; }
+// The schemes a round may use: those that cover the mismatches allowed inside the seed, min(seedmm, maxmm) -- and,
+// where a scheme window can reach beyond a short seed, those that cover the whole-read allowance maxmm -- most
+// specific first, at most ROUND_SCHEMES.
+MG_HD int scheme_rank(const TabDesc& t) { return (4 - tab_m(t)) * tab_B(t) * 8 - tab_m(t); }
+MG_HD RoundSch round_schemes(const LibDev& L, const RoundDev& P) {
+    RoundSch RS; RS.n = 0;
+    const int ms = P.seedmm < P.maxmm ? P.seedmm : P.maxmm;
+    for (int j = 0; j < ROUND_SCHEMES; ++j) { RS.t[j].slot_off = 0; RS.t[j].bits_off = 0; RS.t[j].info = 0; }
+    for (int j = 0; j < L.nsch; ++j) {
+        const TabDesc t = L.sch[j];
+        const int m = tab_m(t);
+        if (!(m == ms || (m == P.maxmm && P.seedlen < 20))) continue;
+        int at = RS.n;
+        while (at > 0 && scheme_rank(RS.t[at - 1]) < scheme_rank(t)) --at;
+        if (at >= ROUND_SCHEMES) continue;
+        for (int q = (RS.n < ROUND_SCHEMES ? RS.n : ROUND_SCHEMES - 1); q > at; --q) RS.t[q] = RS.t[q - 1];
+        RS.t[at] = t;
+        if (RS.n < ROUND_SCHEMES) ++RS.n;
+    }
+    return RS;
+}
+constexpr int PROBE_MAX_LOOK = 6;
 // A read prepared for the probe path.
 struct ProbeRead {
-    uint64_t r[2], c[2];      // forward read / its reverse complement, 2-bit, nt 0 in the low bits
-    int l, s;                 // length after -5/-3, seed length
-    int np;                   // lookups through the contiguous table: pieces, or 2 for a gapped read
-    int ps[2];                // where their k-mers start in the forward read
-    bool gap;                 // the two gapped tables are asked as well
-    bool ok, served;          // ok: bowtie aligns the read at all; served: every lookup is an exact bucket
+    uint64_t r[2];            // the read after -5 / -3, 2-bit, nt 0 in the low bits
+    uint64_t ml[2], ms[2];    // masks (one bit per nt, at even positions) of its l nt / of its s seed nt
+    int l, s;                 // length, seed length
+    TabDesc tab;              // the table(s) its lookups go to: the contiguous one (B = 0) or a scheme's
+    int nlook;                // lookups: pieces, or the scheme's shapes
+    int ps[3];                // plain pieces: where their k-mers start in the read
+    bool lead;                // scheme: shape 0 lies inside the seed, so it finds every stratum-0 alignment
+    bool ok, served;          // ok: bowtie aligns the read at all; served: the probe path can decide it
 };
-MG_HD void probe_setup(const uint64_t* key, const LibDev& L, const RoundDev& P, ProbeRead& R) {
+MG_HD void probe_masks(ProbeRead& R) {
+    R.ml[0] = ones(2 * R.l) & M55; R.ml[1] = ones(2 * R.l - 64) & M55;
+    R.ms[0] = ones(2 * R.s) & M55; R.ms[1] = ones(2 * R.s - 64) & M55;
+}
+// NS = schemes of RS looked at (a template parameter of the kernel: rounds without schemes carry none of it)
+template <int NS>
+MG_HD void probe_setup(const uint64_t* key, const LibDev& L, const RoundDev& P, const RoundSch& RS, ProbeRead& R) {
     Query<2> Q;
-    query_setup<2>(key, P, Q);
-    R.r[0] = Q.q[1].s[0]; R.r[1] = Q.q[1].s[1]; R.c[0] = Q.q[0].s[0]; R.c[1] = Q.q[0].s[1];
-    R.l = Q.l; R.s = Q.s; R.ok = Q.ok;
+    query_setup_fwd<2>(key, P, Q);
+    R.r[0] = Q.q[1].s[0]; R.r[1] = Q.q[1].s[1];
+    R.l = Q.ok ? Q.l : 0; R.s = Q.s; R.ok = Q.ok;
+    probe_masks(R);
+    R.tab = L.ctab; R.nlook = 0; R.lead = false; R.served = false;
+    R.ps[0] = 0; R.ps[1] = 0; R.ps[2] = 0;
+    if (!Q.ok) return;
     const int np = round_np(P);
-    const int cut = np == 2 ? piece_cut(Q.span, 1, 2) : Q.span;       // length of piece 0
-    // gapped (kernels.h: gap_code): two pieces that would both be range queries, >= 16 seed nt, tables present; the
-    // contiguous 12-mers at seed offsets 0 and 4 then take the place of the two pieces
-    R.gap = Q.ok && np == 2 && L.kslotg != nullptr && L.kbg > 0 && L.kb <= 12 && Q.s >= 16 && cut < L.kb;
-    R.np = R.gap ? 2 : np;
-    R.ps[0] = 0; R.ps[1] = R.gap ? 4 : cut;
-    R.served = Q.ok && (R.gap || (cut >= L.kb && (np == 1 || Q.span - cut >= L.kb)));
+    if (piece_cut(Q.span, 1, np) >= L.kb) {                        // the shortest piece is the first: floor(span / np)
+        R.nlook = np; R.served = true;
+#pragma unroll
+        for (int p = 1; p < 3; ++p) R.ps[p] = p < np ? piece_cut(Q.span, p, np) : 0;
+        return;
+    }
+    // a block scheme: its 4B-nt window must lie inside the read, and cover the mismatches allowed there -- inside
+    // the seed min(seedmm, maxmm), else maxmm.  RS is sorted: the first that fits is the most specific.
+    const int ms = P.seedmm < P.maxmm ? P.seedmm : P.maxmm;
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int B = tab_B(RS.t[j]), m = tab_m(RS.t[j]);
+        const bool fits = !found && j < RS.n && 4 * B <= Q.l && m >= (4 * B <= Q.s ? ms : P.maxmm);
+        if (fits) { R.tab = RS.t[j]; found = true; }
+    }
+    if (!found) return;
+    R.nlook = scheme_nshapes(tab_m(R.tab)); R.served = true;
+    R.lead = (4 - tab_m(R.tab)) * tab_B(R.tab) <= Q.s;
 }
-// lookup p (< R.np) in the contiguous table
-MG_HD uint32_t probe_bucket(const ProbeRead& R, const LibDev& L, int p, int& qsf, int& qsr) {
-    Oriented<2> o; o.s[0] = R.r[0]; o.s[1] = R.r[1]; o.n[0] = 0; o.l = R.l;
-    qsf = R.ps[p]; qsr = R.l - R.ps[p] - L.kb;
-    return kmer_code<2>(o, R.ps[p], L.kb);
+// lookup i (< R.nlook): slot index, occupancy bit index (used if tab_bits(R.tab)), and where the looked-up window
+// starts in the read (ps; a scheme's window starts the read)
+MG_HD void probe_lookup(const ProbeRead& R, const LibDev& L, int i, uint32_t& slot, uint32_t& b, int& ps) {
+    const int B = tab_B(R.tab), kbs = tab_kbs(R.tab);
+    if (B == 0) {
+        Oriented<2> o; o.s[0] = R.r[0]; o.s[1] = R.r[1]; o.n[0] = 0; o.l = R.l;
+        ps = i == 0 ? R.ps[0] : (i == 1 ? R.ps[1] : R.ps[2]);
+        b = kmer_code<2>(o, ps, L.kb);
+    } else {
+        const int m = tab_m(R.tab), sel = (4 - m) * B;
+        const uint64_t win = rev2(R.r[0] & ones(8 * B)) >> (64 - 8 * B);   // first 4B nt of the read, first nt most significant
+        b = shape_code(win, B, scheme_shape(m, i)) >> (2 * (sel - kbs));
+        ps = 0;
+        b += (uint32_t)i << (2 * kbs);                                     // shape i's table
+    }
+    slot = R.tab.slot_off + b;
+    b += R.tab.bits_off << 5;
 }
-// lookup in gapped table g (0: read shape 1101, 1: read shape 1011); the bucket index is relative to that table
-MG_HD uint32_t probe_bucket_gap(const ProbeRead& R, const LibDev& L, int g, int& qsf, int& qsr) {
-    const uint32_t c16 = (uint32_t)(rev2((uint64_t)(uint32_t)R.r[0]) >> 32);      // first 16 nt of the forward read, first nt most significant
-    qsf = 0; qsr = R.l - 16;
-    return gap_code(c16, g) >> (2 * (12 - L.kbg));
+// may lookup i be left out, given the best alignment found so far (0 = none)?  Scheme: shape 0 has already found
+// every stratum-0 alignment.  Plain pieces: piece_needed's rule.
+MG_HD bool probe_needed(const ProbeRead& R, const RoundDev& P, int i, uint64_t score) {
+    if (i == 0 || score == 0) return true;
+    if (tab_B(R.tab)) return !(R.lead && (score >> 36) == 4);
+    return piece_needed(P, i, score);
 }
-// One tagged entry against a read: 0 = no alignment, 1 = valid alignment (f, sm, tm, w set).  The entry's context
-// is text[pos - 16, pos + 32); the window starts qs nt before pos, so shifting the context by 16 - qs nt lines text
-// nt w + i up with read nt i.  What the context does not cover is read from the text (window_ok).
-MG_HD int probe_verify(const LibDev& L, const RoundDev& P, const ProbeRead& R, int qsf, int qsr, const KEnt& e,
-                       int& f, int& sm, int& tm, uint32_t& w) {
-    f = (e.pos >> 31) ? 0 : 1;
+// One entry against a read whose lookup started ps nt into it: false = no alignment, true = valid alignment (f, sm,
+// tm, w, ref set).  K = the looked-up window's length.  Forward and (mirrored) reverse entries are judged alike.
+MG_HD bool probe_verify(const RoundDev& P, const ProbeRead& R, int K, int ps, const PEnt& e,
+                        int& f, int& sm, int& tm, uint32_t& w, uint32_t& ref) {
+    // no N, no reference boundary inside the window: it reaches ps nt back from the lookup position and l - ps nt on
+    if (ps > (int)((e.info >> 20) & 63) || R.l - ps > (int)(e.info >> 26)) return false;
+    const int o = PCTX_BACK - ps;                                          // 0 .. 40: context nt the read starts at
+    const uint64_t c0 = (uint64_t)e.c[0] | ((uint64_t)e.c[1] << 32), c1 = (uint64_t)e.c[2] | ((uint64_t)e.c[3] << 32),
+                   c2 = (uint64_t)e.c[4] | ((uint64_t)e.c[5] << 32);
+    const int sh = (2 * o) & 63;
+    const uint64_t y0 = o >= 32 ? c1 : c0, y1 = o >= 32 ? c2 : c1, y2 = o >= 32 ? 0ull : c2;
+    const uint64_t x0 = sh ? (y0 >> sh) | (y1 << (64 - sh)) : y0, x1 = sh ? (y1 >> sh) | (y2 << (64 - sh)) : y1;
+    uint64_t d0 = x0 ^ R.r[0], d1 = x1 ^ R.r[1];
+    d0 = (d0 | (d0 >> 1)) & R.ml[0]; d1 = (d1 | (d1 >> 1)) & R.ml[1];
+    tm = popc64(d0) + popc64(d1);
+    if (tm > P.maxmm) return false;
+    sm = popc64(d0 & R.ms[0]) + popc64(d1 & R.ms[1]);
+    if (sm > P.seedmm) return false;
     const uint32_t pos = e.pos & POS_MASK;
-    const int qs = f ? qsf : qsr, l = R.l;
-    if (pos < (uint32_t)qs) return 0;
-    w = pos - (uint32_t)qs;
-    if (w + (uint32_t)l > L.T) return 0;
-    const int off = CTX_BACK - qs;
-    const uint64_t c64 = (uint64_t)e.c0 | ((uint64_t)e.c1 << 32);
-    uint64_t x0, x1;
-    if (off >= 0) shr128(c64, (uint64_t)e.c2, 2 * off, x0, x1); else shl128(c64, (uint64_t)e.c2, -2 * off, x0, x1);
-    const int a = off < 0 ? -off : 0;
-    int b = CTX_NT - off; if (b > l) b = l;
-    const uint64_t q0 = f ? R.r[0] : R.c[0], q1 = f ? R.r[1] : R.c[1];
-    uint64_t d0 = 0, d1 = 0;
-    if (b > a) {
-        d0 = x0 ^ q0; d0 = (d0 | (d0 >> 1)) & M55 & (ones(2 * b) ^ ones(2 * a));
-        d1 = x1 ^ q1; d1 = (d1 | (d1 >> 1)) & M55 & (ones(2 * b - 64) ^ ones(2 * a - 64));
-        tm = popc64(d0) + popc64(d1);
-        if (tm > P.maxmm) return 0;
-    }
-    uint64_t seedm[2];
-    range_mask<2>(f ? 0 : l - R.s, f ? R.s : l, seedm);
-    if (a == 0 && b == l) {
-        sm = popc64(d0 & seedm[0]) + popc64(d1 & seedm[1]);
-        if (sm > P.seedmm) return 0;
-        return window_clean<2>(L, (int64_t)w, l) ? 1 : 0;
-    }
-    Oriented<2> o; o.s[0] = q0; o.s[1] = q1; o.n[0] = 0; o.l = l;
-    const uint64_t nsp[2] = {0, 0};
-    return window_ok<2, false>(L, o, nsp, seedm, 0, 0, (int64_t)w, P, sm, tm) ? 1 : 0;
+    f = (e.pos >> 31) ? 0 : 1;
+    w = f ? pos - (uint32_t)ps : pos - (uint32_t)(R.l - ps - K);          // >= 0 and w + l <= T follow from dl / dr
+    ref = e.info & (PENT_MAX_REFS - 1);
+    return true;
 }
-// slot -> 0 = empty, 1 = list [lo, hi), 2 = the entry itself
-MG_HD int slot_kind(const KEnt& e, uint32_t& lo, uint32_t& hi) {
+// slot -> 0 = empty, 1 = list [lo, hi) of `pent`, 2 = the entry itself
+MG_HD int slot_kind(const PEnt& e, uint32_t& lo, uint32_t& hi) {
     if (e.pos == SLOT_EMPTY) return 0;
-    if (e.pos == SLOT_LIST) { lo = e.c0; hi = e.c1; return 1; }
+    if (e.pos == SLOT_LIST) { lo = e.info; hi = e.c[0]; return 1; }
     return 2;
 }
-MG_HD KEnt load_slot(const KEnt* __restrict__ slots, uint64_t b) {
-    const uint4 v = *reinterpret_cast<const uint4*>(slots + b);
-    KEnt e; e.pos = v.x; e.c0 = v.y; e.c1 = v.z; e.c2 = v.w;
+MG_HD PEnt load_pent(const PEnt* __restrict__ a, uint64_t i) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* q = reinterpret_cast<const u32x4*>(a + i);
+    const u32x4 v0 = q[0], v1 = q[1];
+    PEnt e; e.pos = v0.x; e.info = v0.y; e.c[0] = v0.z; e.c[1] = v0.w; e.c[2] = v1.x; e.c[3] = v1.y; e.c[4] = v1.z; e.c[5] = v1.w;
     return e;
 }
-MG_HD bool bit_set(const uint32_t* __restrict__ bits, uint32_t b) { return !bits || ((bits[b >> 5] >> (b & 31)) & 1); }
+// the three order keys of an alignment (0 = none): the representative by (stratum, mismatches, position, strand);
+// the largest / smallest reference inside the best stratum -- they differ iff the assignment is ambiguous
+struct ProbeBest { uint64_t score, rmax, rmin; uint32_t ref; };
+MG_HD void probe_record(ProbeBest& Bst, int sm, int tm, uint32_t w, int f, uint32_t ref) {
+    const uint64_t x = hit_score(sm, tm, w, f), y = hit_kmax(sm, ref), z = hit_kmin(sm, ref);
+    if (x > Bst.score) { Bst.score = x; Bst.ref = ref; }
+    Bst.rmax = y > Bst.rmax ? y : Bst.rmax; Bst.rmin = z > Bst.rmin ? z : Bst.rmin;
+}
+MG_HD int tab_K(const TabDesc& t, const LibDev& L) { return tab_B(t) ? 4 * tab_B(t) : L.kb; }
 
 // Serial form of the probe path for one read: false = not served (ask the generic matcher).
-__host__ __device__ inline bool probe_one(const uint64_t* key, const LibDev& L, const RoundDev& P, uint64_t& score, uint64_t& kmax, uint64_t& kmin) {
+__host__ __device__ inline bool probe_one(const uint64_t* key, const LibDev& L, const RoundDev& P, ProbeBest& Bst) {
+    const RoundSch RS = round_schemes(L, P);
     ProbeRead R;
-    probe_setup(key, L, P, R);
-    score = 0; kmax = 0; kmin = 0;
+    probe_setup<ROUND_SCHEMES>(key, L, P, RS, R);
+    Bst.score = 0; Bst.rmax = 0; Bst.rmin = 0; Bst.ref = 0;
     if (!R.ok) return true;                      // bowtie skips the read: served, no alignment
     if (!R.served) return false;
-    bool overflow = false;
-    auto take = [&](const KEnt* slots, const uint32_t* bits, uint32_t b, int qsf, int qsr) {
-        if (!bit_set(bits, b)) return;
-        const KEnt e = load_slot(slots, b);
+    const int K = tab_K(R.tab, L);
+    for (int i = 0; i < R.nlook; ++i) {
+        if (!probe_needed(R, P, i, Bst.score)) continue;
+        uint32_t slot, b; int ps;
+        probe_lookup(R, L, i, slot, b, ps);
+        if (tab_bits(R.tab) && !((L.sbits[b >> 5] >> (b & 31)) & 1)) continue;
+        const PEnt e = load_pent(L.slots, slot);
         uint32_t lo = 0, hi = 0;
         const int kind = slot_kind(e, lo, hi);
-        if (kind == 0) return;
-        if (kind == 1 && hi - lo > (uint32_t)PROBE_MAX_LIST) { overflow = true; return; }
+        if (kind == 0) continue;
+        if (kind == 1 && hi - lo > (uint32_t)PROBE_MAX_LIST) return false;
         for (uint32_t c = lo; c < (kind == 2 ? lo + 1 : hi); ++c) {
-            int f, sm, tm; uint32_t w;
-            if (probe_verify(L, P, R, qsf, qsr, kind == 2 ? e : L.kent[c], f, sm, tm, w) == 1) {
-                uint64_t x = hit_score(sm, tm, w, f), y = hit_kmax(sm, w), z = hit_kmin(sm, w);
-                score = x > score ? x : score; kmax = y > kmax ? y : kmax; kmin = z > kmin ? z : kmin;
-            }
+            int f, sm, tm; uint32_t w, ref;
+            if (probe_verify(P, R, K, ps, kind == 2 ? e : load_pent(L.pent, c), f, sm, tm, w, ref)) probe_record(Bst, sm, tm, w, f, ref);
         }
-    };
-    for (int p = 0; p < R.np; ++p) { int qsf, qsr; const uint32_t b = probe_bucket(R, L, p, qsf, qsr); take(L.kslot, L.kbits2, b, qsf, qsr); }
-    if (R.gap && gap_needed(score))
-        for (int g = 0; g < 2; ++g) {
-            int qsf, qsr; const uint32_t b = probe_bucket_gap(R, L, g, qsf, qsr);
-            take(L.kslotg + (size_t)g * L.gbk, L.kbitsg ? L.kbitsg + (size_t)g * (L.gbk >> 5) : nullptr, b, qsf, qsr);
-        }
-    return !overflow;
+    }
+    return true;
 }
 
 // Serial form of the matcher (one read, all candidates in turn): the definition the kernel below
@@ -917,10 +1058,17 @@ __host__ __device__ inline void match_generic(const uint64_t* key, const LibDev&
 // the generic matcher.
 template <int KW>
 __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, const RoundDev& P, int32_t& ref, uint32_t& amb) {
+    if (KW == 2 && probe_round(L, P)) {
+        ProbeBest Bst;
+        if (probe_one(key, L, P, Bst)) {
+            if (!Bst.score) return false;
+            ref = (int32_t)Bst.ref;
+            amb = (uint32_t)Bst.rmax != 0xFFFFFFFFu - (uint32_t)Bst.rmin;
+            return true;
+        }
+    }
     uint64_t score = 0, kmax = 0, kmin = 0;
-    bool done = false;
-    if (KW == 2 && probe_round(L, P)) done = probe_one(key, L, P, score, kmax, kmin);
-    if (!done) match_generic<KW>(key, L, P, score, kmax, kmin);
+    match_generic<KW>(key, L, P, score, kmax, kmin);
     if (!score) return false;
     ref = (int32_t)ref_of(L, (uint32_t)(score >> 1));
     amb = ref_of(L, (uint32_t)kmax) != ref_of(L, 0xFFFFFFFFu - (uint32_t)kmin);
@@ -1177,31 +1325,39 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
 
 // ------------------------------------------------------------------------------------------
 // The probe path as a kernel (see probe_one for the serial form).  One thread per unique:
-//   1. key, eligibility, the read's two orientations, the buckets of its lookups;
-//   2. occupancy bits of all lookups, then the slots of all lookups with a set bit -- two dependent steps, every
-//      lane with several loads in flight;
+//   1. key, eligibility, the read's two orientations, its lookups (pieces or a block scheme's shapes);
+//   2. two lookups at a time: both occupancy words, then both slots -- two dependent steps, every lane with
+//      several loads in flight;
 //   3. a slot that holds its bucket's only entry is judged on the spot (own results stay in registers); a bucket
-//      list of <= PROBE_MAX_LIST entries is queued in LDS in chunks of four entries;
-//   4. gapped reads that have no stratum-0 alignment yet repeat 2-3 on the two gapped tables;
-//   5. the block drains the queue, sixteen chunks per wave step (lane = chunk x entry), the owner's read coming
-//      from LDS; results meet the owners' through LDS atomic max;
+//      list is queued in LDS: up to 16 entries in chunks of four, longer ones in chunks of 64;
+//   4. reads with more than two lookups (block schemes, three pieces) repeat 2-3 for the next pair, unless what they
+//      have found themselves already rules those lookups out;
+//   5. the block drains the queues -- sixteen 4-entry chunks, or one 64-entry chunk, per wave step (lane = chunk x
+//      entry), the owner's read coming from LDS; results meet the owners' through LDS atomic max;
 //   6. results, survivors -> next round's list, unserved reads -> the fallback list of the generic kernel.
 constexpr int PB = 256;                          // threads per block
-constexpr int PQCAP = 320;                       // queued chunks per block
+// queued chunks per block: rounds of two-mismatch schemes (NS = 3: 6 lookups of 8- or 6-nt specificity) fill them,
+// the others hardly use them
+template <int NS> struct ProbeQ { static constexpr int Q4 = NS >= 3 ? 768 : 320, Q64 = NS >= 3 ? 256 : 32; };
 #ifndef MG_PROBE_WAVES
-#define MG_PROBE_WAVES 8
+#define MG_PROBE_WAVES 6
 #endif
-template <int RN, bool GAPR>
+// chunk: lo = first entry; meta = owner (0-7) | entries - 1 (8-13) | ps (14-19) | K (20-24) | written (31)
+MG_HD uint32_t chunk_meta(uint32_t owner, uint32_t cnt, int ps, int K) {
+    return owner | ((cnt - 1) << 8) | ((uint32_t)ps << 14) | ((uint32_t)K << 20) | 0x80000000u;
+}
+template <int RN, int NS>
 __global__ void __launch_bounds__(PB, MG_PROBE_WAVES)
 k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb,
-              LibDev L, RoundDev P, unsigned long long* stats,
+              LibDev L, RoundDev P, RoundSch RS, unsigned long long* stats,
               const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_n,
               uint32_t* next_list, unsigned long long* next_n, uint32_t* fb_list, unsigned long long* fb_n) {
+    constexpr int PQ4 = ProbeQ<NS>::Q4, PQ64 = ProbeQ<NS>::Q64;
     __shared__ unsigned long long s_best[3 * PB];
     __shared__ uint64_t s_r0[PB], s_r1[PB];
     __shared__ uint32_t s_ls[PB];                // l | s << 8
-    __shared__ uint32_t s_qlo[PQCAP], s_qmeta[PQCAP];       // chunk: first entry; owner (0-7) | entries (8-10) | qsf (11-17) | qsr (18-24)
-    __shared__ uint32_t s_qn, s_wcnt[2][PB / 64], s_base[2];
+    __shared__ uint32_t s_q4lo[PQ4], s_q4meta[PQ4], s_q64lo[PQ64], s_q64meta[PQ64];
+    __shared__ uint32_t s_qn4, s_qn64, s_wcnt[2][PB / 64], s_base[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t n = list ? (uint32_t)*list_n : U;
     if (blockIdx.x * PB >= n) return;
@@ -1222,106 +1378,100 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     }
     if (!__syncthreads_or(active) && !next_list) return;
     s_best[tid] = 0; s_best[PB + tid] = 0; s_best[2 * PB + tid] = 0;
-    for (uint32_t j = tid; j < (uint32_t)PQCAP; j += PB) s_qmeta[j] = 0;
-    if (tid == 0) s_qn = 0;
+    for (uint32_t j = tid; j < (uint32_t)PQ4; j += PB) s_q4meta[j] = 0;       // a chunk that is never written (queue overflow) stays empty
+    for (uint32_t j = tid; j < (uint32_t)PQ64; j += PB) s_q64meta[j] = 0;
+    if (tid == 0) { s_qn4 = 0; s_qn64 = 0; }
     if (!active) { k[0] = 0; k[1] = 0; }                       // an empty read: ok comes out false
     ProbeRead R;
-    probe_setup(k, L, P, R);
+    probe_setup<NS>(k, L, P, RS, R);
     R.ok = R.ok && active;
     const bool run = R.ok && R.served;
     bool fb = R.ok && !R.served;                                // -> the generic kernel
     s_r0[tid] = R.r[0]; s_r1[tid] = R.r[1]; s_ls[tid] = (uint32_t)(R.l & 255) | ((uint32_t)(R.s & 255) << 8);
     __syncthreads();
 
-    uint64_t score = 0, kmax = 0, kmin = 0;                     // what this thread finds itself
+    ProbeBest Bst; Bst.score = 0; Bst.rmax = 0; Bst.rmin = 0; Bst.ref = 0;      // what this thread finds itself
+    const int K = tab_K(R.tab, L);
     // a slot of one lookup: judge the single entry / queue the list
-    auto take = [&](const KEnt& e, int qsf, int qsr) {
+    auto take = [&](const PEnt& e, int ps) {
         uint32_t lo = 0, hi = 0;
         const int kind = slot_kind(e, lo, hi);
         if (kind == 2) {
-            int f, sm, tm; uint32_t w;
-            if (probe_verify(L, P, R, qsf, qsr, e, f, sm, tm, w) == 1) {
-                const uint64_t x = hit_score(sm, tm, w, f), y = hit_kmax(sm, w), z = hit_kmin(sm, w);
-                score = x > score ? x : score; kmax = y > kmax ? y : kmax; kmin = z > kmin ? z : kmin;
-            }
+            int f, sm, tm; uint32_t w, ref;
+            if (probe_verify(P, R, K, ps, e, f, sm, tm, w, ref)) probe_record(Bst, sm, tm, w, f, ref);
         } else if (kind == 1) {
             const uint32_t len = hi - lo;
             if (len > (uint32_t)PROBE_MAX_LIST) { fb = true; return; }
-            const uint32_t nch = (len + 3) >> 2;
-            const uint32_t at = atomicAdd(&s_qn, nch);
-            if (at + nch > (uint32_t)PQCAP) { fb = true; return; }          // a full queue: chunks never written keep 0 entries
-            for (uint32_t c = 0; c < nch; ++c) {
-                const uint32_t cnt = len - 4 * c < 4 ? len - 4 * c : 4;
-                s_qlo[at + c] = lo + 4 * c;
-                s_qmeta[at + c] = tid | (cnt << 8) | ((uint32_t)qsf << 11) | ((uint32_t)qsr << 18);
+            if (len <= 16) {
+                const uint32_t nch = (len + 3) >> 2;
+                const uint32_t at = atomicAdd(&s_qn4, nch);
+                if (at + nch > (uint32_t)PQ4) { fb = true; return; }
+                for (uint32_t c = 0; c < nch; ++c) {
+                    s_q4lo[at + c] = lo + 4 * c;
+                    s_q4meta[at + c] = chunk_meta(tid, len - 4 * c < 4 ? len - 4 * c : 4, ps, K);
+                }
+            } else {
+                const uint32_t nch = (len + 63) >> 6;
+                const uint32_t at = atomicAdd(&s_qn64, nch);
+                if (at + nch > (uint32_t)PQ64) { fb = true; return; }
+                for (uint32_t c = 0; c < nch; ++c) {
+                    s_q64lo[at + c] = lo + 64 * c;
+                    s_q64meta[at + c] = chunk_meta(tid, len - 64 * c < 64 ? len - 64 * c : 64, ps, K);
+                }
             }
         }
     };
-    {
-        uint32_t b[2]; int qsf[2], qsr[2]; bool have[2];
+    // lookups two at a time: both occupancy words, then both slots, then the candidates.  The first pair is
+    // unconditional; later ones are skipped where what this thread has found itself already rules them out.
+    const bool ubits = tab_bits(R.tab);
+    for (int i0 = 0; i0 < PROBE_MAX_LOOK; i0 += 2) {
+        uint32_t slot[2], b[2]; int ps[2]; bool have[2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            have[p] = run && p < R.np;
-            b[p] = 0; qsf[p] = 0; qsr[p] = 0;
-            if (have[p]) b[p] = probe_bucket(R, L, p, qsf[p], qsr[p]);
+        for (int j = 0; j < 2; ++j) {
+            have[j] = run && !fb && i0 + j < R.nlook && probe_needed(R, P, i0 + j, Bst.score);
+            slot[j] = 0; b[j] = 0; ps[j] = 0;
+            if (have[j]) probe_lookup(R, L, i0 + j, slot[j], b[j], ps[j]);
         }
-        if (L.kbits2) {
-            uint32_t wd[2];
+        if (i0 && !__any(have[0] || have[1])) break;
+        uint32_t wd[2];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) wd[p] = have[p] ? L.kbits2[b[p] >> 5] : 0u;
+        for (int j = 0; j < 2; ++j) wd[j] = (have[j] && ubits) ? L.sbits[b[j] >> 5] : 0xFFFFFFFFu;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) have[p] = have[p] && ((wd[p] >> (b[p] & 31)) & 1);
-        }
-        KEnt e[2];
+        for (int j = 0; j < 2; ++j) have[j] = have[j] && ((wd[j] >> (b[j] & 31)) & 1);
+        PEnt e[2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) { e[p].pos = SLOT_EMPTY; e[p].c0 = 0; e[p].c1 = 0; e[p].c2 = 0; if (have[p]) e[p] = load_slot(L.kslot, b[p]); }
+        for (int j = 0; j < 2; ++j) { e[j].pos = SLOT_EMPTY; if (have[j]) e[j] = load_pent(L.slots, slot[j]); }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) if (have[p]) take(e[p], qsf[p], qsr[p]);
-    }
-    if (GAPR) {
-        const bool needg = run && R.gap && !fb && gap_needed(score);
-        if (__any(needg)) {
-            uint32_t b[2]; int qsf[2], qsr[2]; bool have[2];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) { have[g] = needg; b[g] = 0; qsf[g] = 0; qsr[g] = 0; if (needg) b[g] = probe_bucket_gap(R, L, g, qsf[g], qsr[g]); }
-            if (L.kbitsg) {
-                uint32_t wd[2];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) wd[g] = have[g] ? L.kbitsg[(uint32_t)g * (L.gbk >> 5) + (b[g] >> 5)] : 0u;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) have[g] = have[g] && ((wd[g] >> (b[g] & 31)) & 1);
-            }
-            KEnt e[2];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) { e[g].pos = SLOT_EMPTY; e[g].c0 = 0; e[g].c1 = 0; e[g].c2 = 0; if (have[g]) e[g] = load_slot(L.kslotg + (size_t)g * L.gbk, b[g]); }
-#pragma unroll
-            for (int g = 0; g < 2; ++g) if (have[g]) take(e[g], qsf[g], qsr[g]);
-        }
+        for (int j = 0; j < 2; ++j) if (have[j]) take(e[j], ps[j]);
     }
     __syncthreads();
 
     // ---- drain: lane = (chunk, entry); every chunk's owner is told through LDS
+    auto judge = [&](uint32_t meta, uint32_t at) {
+        const uint32_t owner = meta & 255;
+        const PEnt e = load_pent(L.pent, at);
+        ProbeRead O;
+        O.r[0] = s_r0[owner]; O.r[1] = s_r1[owner];
+        O.l = (int)(s_ls[owner] & 255); O.s = (int)((s_ls[owner] >> 8) & 255);
+        probe_masks(O);
+        int f, sm, tm; uint32_t w, ref;
+        if (probe_verify(P, O, (int)((meta >> 20) & 31), (int)((meta >> 14) & 63), e, f, sm, tm, w, ref)) {
+            atomicMax(&s_best[owner], (unsigned long long)hit_score(sm, tm, w, f));
+            atomicMax(&s_best[PB + owner], (unsigned long long)hit_kmax(sm, ref));
+            atomicMax(&s_best[2 * PB + owner], (unsigned long long)hit_kmin(sm, ref));
+        }
+    };
     {
-        const uint32_t qn = s_qn < (uint32_t)PQCAP ? s_qn : (uint32_t)PQCAP;
+        const uint32_t qn = s_qn4 < (uint32_t)PQ4 ? s_qn4 : (uint32_t)PQ4;
         for (uint32_t base = (tid >> 6) * 16; base < qn; base += (PB / 64) * 16) {
             const uint32_t j = base + (lane >> 2), ei = lane & 3;
-            const uint32_t meta = j < qn ? s_qmeta[j] : 0u;
-            if (ei < ((meta >> 8) & 7)) {
-                const uint32_t owner = meta & 255;
-                const KEnt e = L.kent[s_qlo[j] + ei];
-                ProbeRead O;
-                O.r[0] = s_r0[owner]; O.r[1] = s_r1[owner];
-                O.l = (int)(s_ls[owner] & 255); O.s = (int)((s_ls[owner] >> 8) & 255);
-                Oriented<2> fo, ro; fo.s[0] = O.r[0]; fo.s[1] = O.r[1]; fo.n[0] = 0; fo.l = O.l;
-                revcomp<2>(fo, ro);
-                O.c[0] = ro.s[0]; O.c[1] = ro.s[1];
-                int f, sm, tm; uint32_t w;
-                if (probe_verify(L, P, O, (int)((meta >> 11) & 127), (int)((meta >> 18) & 127), e, f, sm, tm, w) == 1) {
-                    atomicMax(&s_best[owner], (unsigned long long)hit_score(sm, tm, w, f));
-                    atomicMax(&s_best[PB + owner], (unsigned long long)hit_kmax(sm, w));
-                    atomicMax(&s_best[2 * PB + owner], (unsigned long long)hit_kmin(sm, w));
-                }
-            }
+            const uint32_t meta = j < qn ? s_q4meta[j] : 0u;
+            if ((meta >> 31) && ei <= ((meta >> 8) & 63)) judge(meta, s_q4lo[j] + ei);
+        }
+        const uint32_t qm = s_qn64 < (uint32_t)PQ64 ? s_qn64 : (uint32_t)PQ64;
+        for (uint32_t j = tid >> 6; j < qm; j += PB / 64) {
+            const uint32_t meta = s_q64meta[j];
+            if ((meta >> 31) && lane <= ((meta >> 8) & 63)) judge(meta, s_q64lo[j] + lane);
         }
     }
     __syncthreads();
@@ -1330,17 +1480,14 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     bool hit = false;
     if (run && !fb) {
         const unsigned long long a = s_best[tid], b2 = s_best[PB + tid], c2 = s_best[2 * PB + tid];
-        score = a > score ? a : score; kmax = b2 > kmax ? b2 : kmax; kmin = c2 > kmin ? c2 : kmin;
-        if (score) {
+        uint32_t ref = Bst.ref;
+        if (a > Bst.score) { Bst.score = a; ref = ref_of(L, (uint32_t)(a >> 1)); }      // the representative came out of a list: its reference from its position
+        Bst.rmax = b2 > Bst.rmax ? b2 : Bst.rmax; Bst.rmin = c2 > Bst.rmin ? c2 : Bst.rmin;
+        if (Bst.score) {
             hit = true;
             ann_round[u] = (uint8_t)(RN + 1);
-            const uint32_t r = ref_of(L, (uint32_t)(score >> 1));
-            ann_ref[u] = (int32_t)r;
-            const uint32_t pmax = (uint32_t)kmax, pmin = 0xFFFFFFFFu - (uint32_t)kmin;
-            const uint32_t r0 = L.ref_start[r], r1 = L.ref_start[r + 1];
-            bool amb = false;
-            if (pmin < r0 || pmax >= r1) amb = ref_of(L, pmax) != ref_of(L, pmin);
-            ann_amb[u] = (uint8_t)amb;
+            ann_ref[u] = (int32_t)ref;
+            ann_amb[u] = (uint8_t)((uint32_t)Bst.rmax != 0xFFFFFFFFu - (uint32_t)Bst.rmin);
         }
     }
     // unserved reads are counted (and listed as survivors, if they stay unaligned) by the generic kernel that takes them

@@ -94,20 +94,22 @@ struct Lib {
     int kb = 0;
     DevBuf text, bad, koff, kent, kpre, kbits, dref, dlut; int lut_shift = 5;
     bool use_bits = true;                // false: koff is small enough to stay in L2, the occupancy bitmap is skipped
-    // both-strand slot tables (LibDev::kslot ...): the contiguous one is built with the library when koff is too large to stay
-    // cache-resident, the two gapped ones the first time a cascade holds a round that can use them (ensure_gapped)
-    DevBuf kslot, kbits2, kslotg, kbitsg; bool has_both = false, use_bits2 = true, use_bits_g = true; int kbg = 0; uint32_t gbk = 0;
+    // both-strand slot tables (LibDev::slots ...): the contiguous one is built with the library, the block-scheme ones
+    // the first time a cascade holds a round that can use them (ensure_schemes); all in two buffers
+    DevBuf slots, sbits, pent; uint64_t n_slots = 0, n_bitw = 0, n_pent = 0; bool has_both = false;
+    TabDesc ctab{0, 0, 0}; std::vector<TabDesc> sch;
     LibDev dev() const {
         LibDev L;
         L.text = text.as<uint64_t>(); L.bad = bad.as<uint64_t>(); L.koff = koff.as<uint32_t>();
         L.kent = kent.as<KEnt>(); L.kpre = kpre.as<uint64_t>(); L.kbits = use_bits ? kbits.as<uint32_t>() : nullptr; L.ref_start = dref.as<uint32_t>();
         L.ref_lut = dlut.as<uint32_t>(); L.lut_shift = lut_shift;
         L.n_refs = (uint32_t)names.size(); L.T = (uint32_t)T; L.kb = kb;
-        L.kslot = has_both ? kslot.as<KEnt>() : nullptr; L.kbits2 = (has_both && use_bits2) ? kbits2.as<uint32_t>() : nullptr;
-        L.kslotg = kbg ? kslotg.as<KEnt>() : nullptr; L.kbitsg = (kbg && use_bits_g) ? kbitsg.as<uint32_t>() : nullptr; L.gbk = gbk; L.kbg = kbg;
+        L.slots = has_both ? slots.as<PEnt>() : nullptr; L.sbits = sbits.as<uint32_t>(); L.pent = pent.as<PEnt>(); L.ctab = ctab;
+        L.nsch = (int)sch.size();
+        for (int j = 0; j < MAX_SCHEMES; ++j) L.sch[j] = j < L.nsch ? sch[j] : TabDesc{0, 0, 0};
         return L;
     }
-    void release() { text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); kslot.release(); kbits2.release(); kslotg.release(); kbitsg.release(); kbg = 0; has_both = false; loaded = false; }
+    void release() { text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); slots.release(); sbits.release(); pent.release(); sch.clear(); n_slots = n_bitw = n_pent = 0; has_both = false; loaded = false; }
 };
 
 constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
@@ -243,59 +245,68 @@ bool bits_wanted(uint64_t nbk) {                 // an occupancy bitmap in front
     if (const char* env = getenv("MIRGE_BITS2_MAX")) lim = strtoull(env, nullptr, 10);
     return nbk / 8 <= lim;
 }
-// One table: 2T entries (every position under its own key and under the reverse strand's) at entry offset `base` of
-// kent / kpre, which must have room; nbk = 4^k slots and nbk / 32 occupancy words into the given buffers.
-int build_both(mirge_ctx* c, Lib& L, int k, int shape, uint64_t base, KEnt* slots, uint32_t* bits) {
-    const uint64_t nbk = 1ull << (2 * k), T = L.T;
+// One table: 2T entries (every position under its own key and under the reverse strand's) appended to `pent`, nbk = 4^k
+// slots and nbk / 32 occupancy words appended to the library's slot / occupancy buffers (all grown here).
+// B = 0: the contiguous k-mer table; else the table of one shape (block mask) of a block scheme.
+int build_both(mirge_ctx* c, Lib& L, int k, int B, uint32_t mask) {
+    const uint64_t nbk = 1ull << (2 * k), T = L.T, base = L.n_pent;
+    if (base + 2 * T >= 0xFFFFFFF0ull || L.n_slots + nbk >= 0xFFFFFFF0ull || L.n_bitw + nbk / 32 >= (1ull << 27))
+        return fail(c, MIRGE_E_LIMIT, "seed tables of a library exceed 2^32 entries");
+    HIPCHK(c, L.pent.ensure((base + 2 * T) * sizeof(PEnt), true, base * sizeof(PEnt), c->st));
+    HIPCHK(c, L.slots.ensure((L.n_slots + nbk) * sizeof(PEnt), true, L.n_slots * sizeof(PEnt), c->st));
+    HIPCHK(c, L.sbits.ensure((L.n_bitw + nbk / 32 + 1) * 4, true, L.n_bitw * 4, c->st));
     HIPCHK(c, c->hist.ensure((nbk + 1) * 4, false, 0, c->st));
     HIPCHK(c, c->off_tmp.ensure((nbk + 1) * 4, false, 0, c->st));
     HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (nbk + 1) * 4, c->st));
     const uint32_t grid = (uint32_t)((T + 255) / 256);
-    hipLaunchKernelGGL(k_both_hist, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, k, shape, c->hist.as<uint32_t>());
-    hipLaunchKernelGGL(k_bucket_bits, dim3((uint32_t)((nbk / 32 + 256) / 256)), dim3(256), 0, c->st, c->hist.as<uint32_t>(), nbk, bits);
+    hipLaunchKernelGGL(k_both_hist, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, k, B, mask, c->hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_bucket_bits, dim3((uint32_t)((nbk / 32 + 256) / 256)), dim3(256), 0, c->st, c->hist.as<uint32_t>(), nbk, L.sbits.as<uint32_t>() + L.n_bitw);
     int rc = scan_exclusive(c, c->hist.as<uint32_t>(), c->off_tmp.as<uint32_t>(), nbk + 1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_add_u32, dim3((uint32_t)((nbk + 1 + 255) / 256)), dim3(256), 0, c->st, c->off_tmp.as<uint32_t>(), nbk + 1, (uint32_t)base);
     HIPCHK(c, hipMemcpyAsync(c->hist.p, c->off_tmp.p, nbk * 4, hipMemcpyDeviceToDevice, c->st));
-    hipLaunchKernelGGL(k_both_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, k, shape, c->hist.as<uint32_t>(),
-                       L.kent.as<KEnt>(), L.kpre.as<uint64_t>());
-    hipLaunchKernelGGL(k_slot_fill, dim3((uint32_t)((nbk + 255) / 256)), dim3(256), 0, c->st, c->off_tmp.as<uint32_t>(), L.kent.as<KEnt>(), nbk, slots);
+    hipLaunchKernelGGL(k_both_scatter, dim3(grid), dim3(256), 0, c->st, L.dev(), k, B, mask, c->hist.as<uint32_t>(), L.pent.as<PEnt>());
+    hipLaunchKernelGGL(k_slot_fill, dim3((uint32_t)((nbk + 255) / 256)), dim3(256), 0, c->st, c->off_tmp.as<uint32_t>(), L.pent.as<PEnt>(), nbk, L.slots.as<PEnt>() + L.n_slots);
     HIPCHK(c, hipGetLastError());
+    L.n_pent = base + 2 * T; L.n_slots += nbk; L.n_bitw += nbk / 32;
     return MIRGE_OK;
 }
 // the contiguous table, with the library
 int build_contig_both(mirge_ctx* c, Lib& L) {
-    const uint64_t nbk = 1ull << (2 * L.kb), T = L.T;
-    if (T == 0 || 3 * T >= 0xFFFFFFF0ull) return MIRGE_OK;
-    HIPCHK(c, L.kent.ensure(3 * T * sizeof(KEnt), true, T * sizeof(KEnt), c->st));
-    HIPCHK(c, L.kpre.ensure(3 * T * 8, true, T * 8, c->st));
-    HIPCHK(c, L.kslot.ensure(nbk * sizeof(KEnt), false, 0, c->st));
-    HIPCHK(c, L.kbits2.ensure((nbk / 32 + 1) * 4, false, 0, c->st));
-    int rc = build_both(c, L, L.kb, 0, T, L.kslot.as<KEnt>(), L.kbits2.as<uint32_t>());
+    if (L.T == 0 || L.names.size() > PENT_MAX_REFS) return MIRGE_OK;      // an entry holds its reference in 20 bits
+    const uint64_t nbk = 1ull << (2 * L.kb);
+    L.ctab = TabDesc{(uint32_t)L.n_slots, (uint32_t)L.n_bitw, tab_info(L.kb, 0, 0, bits_wanted(nbk))};
+    int rc = build_both(c, L, L.kb, 0, 0u);
     if (rc) return rc;
-    L.use_bits2 = bits_wanted(nbk);
     L.has_both = true;
     return MIRGE_OK;
 }
-// The two gapped tables (kernels.h: gap_code), built the first time a cascade holds a round that can use them -- a
-// two-piece round (<= 1 seed mismatch) against a library that has the contiguous table.
-int ensure_gapped(mirge_ctx* c, Lib& L) {
-    if (L.kbg || !L.loaded || !L.has_both || L.kb < 9 || L.T == 0 || 7 * L.T >= 0xFFFFFFF0ull) return MIRGE_OK;
-    if (const char* env = getenv("MIRGE_GAPPED")) { if (atoi(env) == 0) return MIRGE_OK; }      // A/B aid
-    const int kbg = std::min(L.kb, 12);
-    const uint64_t gbk = 1ull << (2 * kbg), T = L.T;
-    HIPCHK(c, L.kent.ensure(7 * T * sizeof(KEnt), true, 3 * T * sizeof(KEnt), c->st));
-    HIPCHK(c, L.kpre.ensure(7 * T * 8, true, 3 * T * 8, c->st));
-    HIPCHK(c, L.kslotg.ensure(2 * gbk * sizeof(KEnt), false, 0, c->st));
-    HIPCHK(c, L.kbitsg.ensure(2 * (gbk / 32) * 4 + 4, false, 0, c->st));
-    for (int g = 0; g < 2; ++g) {
-        int rc = build_both(c, L, kbg, g + 1, (3 + 2 * (uint64_t)g) * T, L.kslotg.as<KEnt>() + (size_t)g * gbk, L.kbitsg.as<uint32_t>() + (size_t)g * (gbk / 32));
-        if (rc) return rc;
-    }
+// Block scheme (B, m) of a library (kernels.h: block schemes), built the first time a cascade holds a round that can use it.
+int ensure_scheme(mirge_ctx* c, Lib& L, int B, int m) {
+    if (!L.loaded || !L.has_both || L.T == 0) return MIRGE_OK;
+    for (auto& x : L.sch) if (tab_B(x) == B && tab_m(x) == m) return MIRGE_OK;
+    if ((int)L.sch.size() >= MAX_SCHEMES) return MIRGE_OK;
+    const int ns = scheme_nshapes(m), kbs = std::min((4 - m) * B, L.kb);
+    const uint64_t nbk = 1ull << (2 * kbs);
+    if (L.n_pent + (uint64_t)ns * 2 * L.T >= 0xFFFFFFF0ull || L.n_slots + ns * nbk >= 0xFFFFFFF0ull) return MIRGE_OK;    // too large a library: its short reads stay with the generic kernel
+    const TabDesc t{(uint32_t)L.n_slots, (uint32_t)L.n_bitw, tab_info(kbs, B, m, bits_wanted(nbk))};
+    for (int i = 0; i < ns; ++i) { int rc = build_both(c, L, kbs, B, scheme_shape(m, i)); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->st));
-    L.use_bits_g = bits_wanted(gbk);
-    L.kbg = kbg; L.gbk = (uint32_t)gbk;
+    L.sch.push_back(t);
     return MIRGE_OK;
+}
+// the schemes a round can use: B = 4 for one mismatch (12-nt shapes), B = 3, 4, 5 for two (6 / 8 / 10-nt shapes)
+int ensure_schemes(mirge_ctx* c, Lib& L, const mirge_round& R) {
+    if (const char* env = getenv("MIRGE_SCHEMES")) { if (atoi(env) == 0) return MIRGE_OK; }      // A/B aid
+    const int ms = std::min(R.seedmm, R.maxmm);
+    int rc = MIRGE_OK;
+    auto want = [&](int m) {
+        if (m == 1 && !rc) rc = ensure_scheme(c, L, 4, 1);
+        if (m == 2) for (int B = 5; B >= 3 && !rc; --B) rc = ensure_scheme(c, L, B, 2);
+    };
+    want(ms);
+    if (R.maxmm != ms && R.seedlen < 20) want(R.maxmm);         // windows that reach beyond a short seed fall under the whole-read allowance
+    return rc;
 }
 
 // ---- library: host packing + device index build
@@ -329,7 +340,7 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     for (auto& nm : L.names) { size_t e = nm.find_first_of(" \t"); L.short_names.push_back(e == std::string::npos ? nm : nm.substr(0, e)); }
     int kb = (int)std::lround(std::log2((double)std::max<uint64_t>(T, 16)) / 2.0) + 1;   // ~0.25 random entries per bucket
     L.kb = std::min(14, std::max(4, kb));
-    L.use_bits = true; L.kbg = 0; L.gbk = 0; L.has_both = false;
+    L.use_bits = true; L.has_both = false; L.sch.clear(); L.n_slots = L.n_bitw = L.n_pent = 0;
     if (const char* env = getenv("MIRGE_KB_BIAS")) L.kb = std::min(14, std::max(4, L.kb + atoi(env)));   // tuning aid
     if (const char* env = getenv("MIRGE_KB")) { if (atoi(env) >= 2 && atoi(env) <= 15) L.kb = atoi(env); }   // tests
     uint64_t nb = 1ull << (2 * L.kb);
@@ -365,7 +376,7 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
         HIPCHK(c, hipMemcpyAsync(c->hist.p, L.koff.p, nb * 4, hipMemcpyDeviceToDevice, c->st));
         hipLaunchKernelGGL(k_kmer_scatter, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, L.kb, c->hist.as<uint32_t>(), L.kent.as<KEnt>(), L.kpre.as<uint64_t>());
         HIPCHK(c, hipGetLastError());
-        int min_kb = 11;                                              // koff of 4^11 + 1 words = 16 MB: not cache-resident any more
+        int min_kb = 9;
         if (const char* env = getenv("MIRGE_SLOTS_MIN_KB")) min_kb = atoi(env);
         if (L.kb >= min_kb && want_slots()) { rc = build_contig_both(c, L); if (rc) return rc; }
     } else {
@@ -932,11 +943,11 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
     if (KW == 2 && probe_round(L, P)) {
         // the probe path (kernels.h: k_probe_round) for what the slot tables can serve, then the generic kernel over the
         // reads it handed on -- its grid covers the worst case, blocks beyond the list's length leave at once
-        const bool gapr = L.kslotg != nullptr && L.kbg > 0 && L.kb <= 12 && round_np(P) == 2;
-        auto kern = gapr ? k_probe_round<RN, true> : k_probe_round<RN, false>;
+        const RoundSch RS = round_schemes(L, P);
+        auto kern = RS.n == 0 ? k_probe_round<RN, 0> : (RS.n == 1 ? k_probe_round<RN, 1> : k_probe_round<RN, ROUND_SCHEMES>);
         hipLaunchKernelGGL(kern, dim3((uint32_t)((C.U + PB - 1) / PB)), dim3(PB), 0, C.st,
                            C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), C.ann_amb.as<uint8_t>(),
-                           L, P, c->d_stats + (size_t)r * STAT_WORDS, list, C.act_n + r, next_list, C.act_n + r + 1,
+                           L, P, RS, c->d_stats + (size_t)r * STAT_WORDS, list, C.act_n + r, next_list, C.act_n + r + 1,
                            C.fb.as<uint32_t>(), C.fb_n + r);
         hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((C.U + MB - 1) / MB)), dim3(MB), 0, C.st,
                            C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
@@ -1003,7 +1014,7 @@ int annotate(mirge_ctx* c) {
     if (!c->libs[MIRGE_LIB_MIRNA].loaded) return fail(c, MIRGE_E_ARG, "mirna library not loaded");
     for (int r = 0; r < c->n_rounds; ++r) {
         const mirge_round& R = c->rounds[r];
-        if (std::min(R.seedmm, R.maxmm) == 1) { int rc = ensure_gapped(c, c->libs[R.lib]); if (rc) return rc; }
+        int rc = ensure_schemes(c, c->libs[R.lib], R); if (rc) return rc;
     }
     kt_clear(c, "match"); kt_clear(c, "counts");
     // Round 1 walks the whole table and leaves every unique's annotation state behind (k_match_round<KW, 0>), so

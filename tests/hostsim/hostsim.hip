@@ -15,17 +15,19 @@ struct SimLib {
     std::vector<uint64_t> text, bad;
     std::vector<uint32_t> koff, ref_start, kbits, lut; int lut_shift = 5; std::vector<KEnt> kent; std::vector<uint64_t> kpre;
     uint32_t T; int kb;
-    std::vector<KEnt> kslot, kslotg; std::vector<uint32_t> kbits2, kbitsg; int kbg = 0; uint32_t gbk = 0;
+    std::vector<PEnt> slots, pent; std::vector<uint32_t> sbits; TabDesc ctab{0, 0, 0}; std::vector<TabDesc> sch;
     LibDev dev() const { LibDev L; L.text = text.data(); L.bad = bad.data(); L.koff = koff.data(); L.kent = kent.data(); L.kpre = kpre.data(); L.kbits = kbits.data();
                          L.ref_start = ref_start.data(); L.ref_lut = lut.data(); L.lut_shift = lut_shift; L.n_refs = (uint32_t)ref_start.size() - 1; L.T = T; L.kb = kb;
-                         L.kslot = kslot.empty() ? nullptr : kslot.data(); L.kbits2 = kbits2.empty() ? nullptr : kbits2.data();
-                         L.kslotg = kbg ? kslotg.data() : nullptr; L.kbitsg = kbg ? kbitsg.data() : nullptr; L.gbk = gbk; L.kbg = kbg; return L; }
+                         L.slots = slots.empty() ? nullptr : slots.data(); L.sbits = sbits.data(); L.pent = pent.data(); L.ctab = ctab;
+                         L.nsch = (int)sch.size();
+                         for (int j = 0; j < MAX_SCHEMES; ++j) L.sch[j] = j < L.nsch ? sch[j] : TabDesc{0, 0, 0};
+                         return L; }
 };
 
 extern "C" {
 
 // same layout rules as load_library() in mirge_hip.hip; index built with text_kmer()
-// flags bit 0: the both-strand slot tables as well (LibDev::kslot; the gapped ones too when kb >= 9), bit 1: no occupancy bits in front of them
+// flags bit 0: the both-strand slot tables as well (LibDev::kslot, and the block schemes (4,1), (5,2), (4,2), (3,2)), bit 1: no occupancy bits in front of them
 void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb, int32_t flags) {
     SimLib* S = new SimLib();
     uint64_t T = 0;
@@ -53,37 +55,42 @@ void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb,
     for (uint64_t b = 0; b < nb; ++b) S->koff[b + 1] += S->koff[b];
     std::vector<uint32_t> cur(S->koff.begin(), S->koff.end() - 1);
     for (uint32_t q = 0; q < T; ++q) S->kent[cur[text_kmer(S->text.data(), q, kb)]++] = make_kent(S->text.data(), q);
-    // both-strand slot tables, laid out as build_contig_both() / ensure_gapped() in mirge_hip.hip do
+    // both-strand slot tables, laid out as build_contig_both() / ensure_scheme() in mirge_hip.hip do
     if ((flags & 1) && T > 0) {
-        auto build = [&](int k, int shape, uint64_t base, KEnt* slots, uint32_t* bits) {
-            const uint64_t nbk = 1ull << (2 * k);
+        const bool ubits = !(flags & 2);
+        const LibDev LD = S->dev();                                      // text, N bitmap and reference offsets are in place
+        auto build = [&](int k, int B, uint32_t mask) {
+            const uint64_t nbk = 1ull << (2 * k), base = S->pent.size(), s0 = S->slots.size(), w0 = S->sbits.size();
+            const int K = B ? 4 * B : k;
+            S->pent.resize(base + 2 * (size_t)T);
+            S->slots.resize(s0 + nbk); S->sbits.resize(w0 + nbk / 32, 0);
             std::vector<uint32_t> off(nbk + 1, 0);
-            for (uint32_t q = 0; q < T; ++q) { uint32_t bf, br; both_buckets(S->text.data(), q, k, shape, bf, br); off[bf + 1]++; off[br + 1]++; }
-            for (uint64_t b = 0; b < nbk; ++b) { if (off[b + 1] && bits) bits[b >> 5] |= 1u << (b & 31); off[b + 1] += off[b]; }
+            for (uint32_t q = 0; q < T; ++q) { uint32_t bf, br; both_buckets(S->text.data(), q, k, B, mask, bf, br); off[bf + 1]++; off[br + 1]++; }
+            for (uint64_t b = 0; b < nbk; ++b) { if (off[b + 1]) S->sbits[w0 + (b >> 5)] |= 1u << (b & 31); off[b + 1] += off[b]; }
             for (auto& o : off) o += (uint32_t)base;
             std::vector<uint32_t> cur2(off.begin(), off.end() - 1);
             for (uint32_t q = 0; q < T; ++q) {
-                uint32_t bf, br; both_buckets(S->text.data(), q, k, shape, bf, br);
-                KEnt e = make_kent(S->text.data(), q);
-                S->kent[cur2[bf]++] = e; e.pos = q | POS_REV; S->kent[cur2[br]++] = e;
+                uint32_t bf, br; both_buckets(S->text.data(), q, k, B, mask, bf, br);
+                S->pent[cur2[bf]++] = make_pent(LD, q, K, false); S->pent[cur2[br]++] = make_pent(LD, q, K, true);
             }
             for (uint64_t b = 0; b < nbk; ++b) {                        // as k_slot_fill
                 const uint32_t lo = off[b], hi = off[b + 1];
-                if (hi == lo) slots[b] = KEnt{SLOT_EMPTY, 0, 0, 0};
-                else if (hi == lo + 1) slots[b] = S->kent[lo];
-                else slots[b] = KEnt{SLOT_LIST, lo, hi, 0};
+                PEnt e{}; 
+                if (hi == lo) e.pos = SLOT_EMPTY;
+                else if (hi == lo + 1) e = S->pent[lo];
+                else { e.pos = SLOT_LIST; e.info = lo; e.c[0] = hi; }
+                S->slots[s0 + b] = e;
             }
         };
-        const bool gapped = kb >= 9;
-        S->kent.resize((gapped ? 7 : 3) * (size_t)T, KEnt{0, 0, 0, 0});
-        S->kslot.resize(nb); if (!(flags & 2)) S->kbits2.assign(nb / 32 + 1, 0);
-        build(kb, 0, T, S->kslot.data(), (flags & 2) ? nullptr : S->kbits2.data());
-        if (gapped) {
-            const int kbg = std::min(kb, 12); const uint64_t gbk = 1ull << (2 * kbg);
-            S->kslotg.resize(2 * gbk); S->kbitsg.assign(2 * (gbk / 32), 0);
-            for (int g = 0; g < 2; ++g) build(kbg, g + 1, (3 + 2 * (uint64_t)g) * T, S->kslotg.data() + (size_t)g * gbk, S->kbitsg.data() + (size_t)g * (gbk / 32));
-            S->kbg = kbg; S->gbk = (uint32_t)gbk;
+        S->ctab = TabDesc{0, 0, tab_info(kb, 0, 0, ubits)};
+        build(kb, 0, 0u);
+        const int BM[4][2] = {{4, 1}, {5, 2}, {4, 2}, {3, 2}};
+        for (int j = 0; j < 4; ++j) {
+            const int B = BM[j][0], m = BM[j][1], kbs = std::min((4 - m) * B, kb);
+            S->sch.push_back(TabDesc{(uint32_t)S->slots.size(), (uint32_t)S->sbits.size(), tab_info(kbs, B, m, ubits)});
+            for (int i = 0; i < scheme_nshapes(m); ++i) build(kbs, B, scheme_shape(m, i));
         }
+        S->sbits.push_back(0);
     }
     S->kpre.assign(S->kent.size(), 0);
     for (size_t i = 0; i < S->kent.size(); ++i) S->kpre[i] = make_kpre(S->kent[i]);
