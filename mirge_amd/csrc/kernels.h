@@ -310,6 +310,195 @@ k_collapse_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Partitioned collapse (16-byte keys; BASELINE.json's "LDS-staged" collapse in hash form).  The table form above pays
+// one device-scope compare-and-swap and ~3 random lines per distinct key; at the bench's U/N = 0.55 that is what its
+// 0.9 ms are made of.  Here the reads are split by hash bits in two streaming passes of small fan-out (64, then 256)
+// into partitions that fit the LDS, and each partition is folded by one workgroup:
+//   k_part_pass : a tile of 2048 records -> duplicates folded in an LDS table (one record per tile and sequence: the
+//                 heavy hitters of miRNA-seq never reach the next pass more than once per tile) -> the tile's distinct
+//                 records ranked per bucket in LDS -> ONE global atomic per tile and bucket reserves their run in the
+//                 bucket's region -> 16-byte scattered stores, which the L2 combines into whole lines;
+//   k_part_fold : one final partition (<= PT_C2 records) in LDS -> folded -> its uniques appended to the table as
+//                 k_collapse_emit does (one packed atomic per partition).
+// Regions have fixed capacities; a pass that would overrun one raises `overflow` and the host runs the table form.
+#ifndef MG_PT_TILE
+#define MG_PT_TILE 2048
+#endif
+#ifndef MG_PT_P2
+#define MG_PT_P2 256
+#endif
+#ifndef MG_PT_C2
+#define MG_PT_C2 2048
+#endif
+constexpr int PT_TILE = MG_PT_TILE, PT_BLOCK = 1024;
+constexpr int PT_P2 = MG_PT_P2;                  // fan-out of pass 2 (pass 1: 64 .. 512, by input size)
+constexpr int PT_C2 = MG_PT_C2;                  // records a final partition may hold
+constexpr int pt_log2(int x) { return x <= 1 ? 0 : 1 + pt_log2(x / 2); }
+// hash bits: pass 1 takes the top log2(P1) bits, pass 2 the log2(P2) below them (far above what the LDS tables use)
+inline int pt_shift1(int p1) { return 64 - pt_log2(p1); }
+inline int pt_shift2(int p1) { return 64 - pt_log2(p1) - pt_log2(PT_P2); }
+template <int NB>
+__global__ void __launch_bounds__(PT_BLOCK)
+k_part_pass(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ wt_in, const unsigned long long* __restrict__ n_in, uint32_t n_max,
+            uint32_t in_stride, int shift, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ wt_out, unsigned long long* cursor,
+            uint32_t cap_out, unsigned long long* overflow) {
+    // blockIdx.y = input partition (its records start in_stride records further on; n_in[p] of them, at most n_max),
+    // blockIdx.x = tile.  wt_in (nullable) = a count per input record.
+    __shared__ uint64_t tk[PT_TILE * 2];
+    __shared__ uint32_t towner[2 * PT_TILE];
+    __shared__ uint32_t tcnt[PT_TILE];
+    __shared__ uint32_t hist[NB], gbase[NB];
+    constexpr int PER = PT_TILE / PT_BLOCK;
+    const uint32_t tid = threadIdx.x, p = blockIdx.y;
+    uint32_t n = n_in ? (uint32_t)(n_in[p] < n_max ? n_in[p] : n_max) : n_max;
+    const uint32_t base = blockIdx.x * (uint32_t)PT_TILE;
+    if (base >= n) return;
+    const uint32_t nvalid = n - base < (uint32_t)PT_TILE ? n - base : (uint32_t)PT_TILE;
+    const uint64_t* kin = keys_in + (uint64_t)p * in_stride * 2 + (uint64_t)base * 2;
+    const uint32_t* win = wt_in ? wt_in + (uint64_t)p * in_stride + base : nullptr;
+    for (uint32_t j = tid; j < (uint32_t)(PT_TILE * 2); j += PT_BLOCK) tk[j] = j < nvalid * 2 ? kin[j] : 0ull;
+    for (uint32_t j = tid; j < 2u * PT_TILE; j += PT_BLOCK) towner[j] = EMPTY;
+    for (uint32_t j = tid; j < (uint32_t)PT_TILE; j += PT_BLOCK) tcnt[j] = 0;
+    if (tid < (uint32_t)NB) hist[tid] = 0;
+    __syncthreads();
+    uint32_t trep[PER]; uint64_t h64[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const uint32_t idx = tid + e * PT_BLOCK;
+        trep[e] = EMPTY; h64[e] = 0;
+        if (idx < nvalid) {
+            uint64_t k[2] = {tk[idx * 2], tk[idx * 2 + 1]};
+            h64[e] = key_hash64<2>(k);
+            uint32_t h = (uint32_t)h64[e] & (2u * PT_TILE - 1);
+            for (;;) {
+                const uint32_t o = atomicCAS(&towner[h], EMPTY, idx);
+                if (o == EMPTY) { trep[e] = idx; break; }
+                if (tk[o * 2] == k[0] && tk[o * 2 + 1] == k[1]) { trep[e] = o; break; }
+                h = (h + 1) & (2u * PT_TILE - 1);
+            }
+            atomicAdd(&tcnt[trep[e]], win ? win[idx] : 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t rank[PER], bk[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const uint32_t idx = tid + e * PT_BLOCK;
+        rank[e] = EMPTY; bk[e] = 0;
+        if (idx < nvalid && trep[e] == idx) { bk[e] = (uint32_t)(h64[e] >> shift) & (NB - 1); rank[e] = atomicAdd(&hist[bk[e]], 1u); }
+    }
+    __syncthreads();
+    if (tid < (uint32_t)NB) {
+        const uint32_t c = hist[tid];
+        unsigned long long at = 0;
+        if (c) {
+            at = atomicAdd(&cursor[(uint64_t)p * NB + tid], (unsigned long long)c);
+            if (at + c > cap_out) *overflow = 1ull;
+        }
+        gbase[tid] = (uint32_t)(at < cap_out ? at : cap_out);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const uint32_t idx = tid + e * PT_BLOCK;
+        if (rank[e] == EMPTY) continue;
+        const uint64_t at = (uint64_t)gbase[bk[e]] + rank[e];
+        if (at >= cap_out) continue;                            // overflow: flagged above, the host starts over in table form
+        const uint64_t o = ((uint64_t)p * NB + bk[e]) * cap_out + at;
+        keys_out[o * 2] = tk[idx * 2]; keys_out[o * 2 + 1] = tk[idx * 2 + 1];
+        wt_out[o] = tcnt[idx];
+    }
+}
+__global__ void __launch_bounds__(PT_BLOCK)
+k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ wt_in, const unsigned long long* __restrict__ n_in,
+            const uint32_t* __restrict__ gslots, uint32_t gmask, uint64_t* ukeys, uint32_t U0,
+            uint32_t* coo_g, uint32_t* coo_c, unsigned long long* ctr) {
+    __shared__ uint64_t tk[PT_C2 * 2];
+    __shared__ uint32_t towner[2 * PT_C2];
+    __shared__ uint32_t tcnt[PT_C2];
+    __shared__ uint32_t s_scan[PT_BLOCK];
+    __shared__ uint32_t s_base[2];
+    constexpr int PER = PT_C2 / PT_BLOCK;
+    const uint32_t tid = threadIdx.x, q = blockIdx.x;
+    const uint32_t nvalid = (uint32_t)(n_in[q] < (unsigned long long)PT_C2 ? n_in[q] : (unsigned long long)PT_C2);
+    if (nvalid == 0) return;
+    const uint64_t* kin = keys_in + (uint64_t)q * PT_C2 * 2;
+    const uint32_t* win = wt_in + (uint64_t)q * PT_C2;
+    for (uint32_t j = tid; j < nvalid * 2; j += PT_BLOCK) tk[j] = kin[j];
+    for (uint32_t j = tid; j < 2u * PT_C2; j += PT_BLOCK) towner[j] = EMPTY;
+    for (uint32_t j = tid; j < (uint32_t)PT_C2; j += PT_BLOCK) tcnt[j] = 0;
+    __syncthreads();
+    uint32_t trep[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const uint32_t idx = tid + e * PT_BLOCK;
+        trep[e] = EMPTY;
+        if (idx < nvalid) {
+            uint64_t k[2] = {tk[idx * 2], tk[idx * 2 + 1]};
+            uint32_t h = key_hash<2>(k) & (2u * PT_C2 - 1);
+            for (;;) {
+                const uint32_t o = atomicCAS(&towner[h], EMPTY, idx);
+                if (o == EMPTY) { trep[e] = idx; break; }
+                if (tk[o * 2] == k[0] && tk[o * 2 + 1] == k[1]) { trep[e] = o; break; }
+                h = (h + 1) & (2u * PT_C2 - 1);
+            }
+            atomicAdd(&tcnt[trep[e]], win[idx]);
+        }
+    }
+    __syncthreads();
+    // representatives -> (unique id, count) entries; ids of sequences an earlier sample brought come from the
+    // cross-sample table, the others are appended (as k_collapse_emit)
+    uint32_t g[PER];
+    uint32_t nrep = 0, nnew = 0;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const uint32_t idx = tid + e * PT_BLOCK;
+        g[e] = EMPTY;
+        const bool rep = idx < nvalid && trep[e] == idx;
+        if (rep && gslots) {
+            const uint64_t k[2] = {tk[idx * 2], tk[idx * 2 + 1]};
+            uint32_t h = slot_hash<2>(k) & gmask;
+            for (;;) {
+                const uint32_t o = gslots[h];
+                if (o == EMPTY) break;
+                if (ukeys[(uint64_t)o * 2] == k[0] && ukeys[(uint64_t)o * 2 + 1] == k[1]) { g[e] = o; break; }
+                h = (h + 1) & gmask;
+            }
+        }
+        nrep += rep; nnew += rep && g[e] == EMPTY;
+        if (!rep) trep[e] = EMPTY;                              // from here on: EMPTY = not a representative
+    }
+    s_scan[tid] = nrep | (nnew << 16);
+    __syncthreads();
+    for (int o = 1; o < PT_BLOCK; o <<= 1) {
+        const uint32_t t = (int)tid >= o ? s_scan[tid - o] : 0u;
+        __syncthreads();
+        s_scan[tid] += t;
+        __syncthreads();
+    }
+    const uint32_t incl = s_scan[tid];
+    if (tid == PT_BLOCK - 1) {
+        const uint32_t trp = incl & 0xFFFF, tnw = incl >> 16;
+        const unsigned long long old = atomicAdd(&ctr[0], ((unsigned long long)tnw << 32) | trp);
+        s_base[0] = (uint32_t)old; s_base[1] = (uint32_t)(old >> 32);
+    }
+    __syncthreads();
+    uint32_t prep = s_base[0] + (incl & 0xFFFF) - nrep, pnew = s_base[1] + (incl >> 16) - nnew;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        if (trep[e] == EMPTY) continue;
+        const uint32_t idx = tid + e * PT_BLOCK;
+        uint32_t gg = g[e];
+        if (gg == EMPTY) {
+            gg = U0 + pnew++;
+            ukeys[(uint64_t)gg * 2] = tk[idx * 2]; ukeys[(uint64_t)gg * 2 + 1] = tk[idx * 2 + 1];
+        }
+        coo_g[prep] = gg; coo_c[prep] = tcnt[idx];
+        ++prep;
+    }
+}
+
 // collapse, step C: insert uniques [g0, g1) into the cross-sample table.  They are distinct from
 // each other and from everything already there, so a bare claim suffices.
 template <int KW>

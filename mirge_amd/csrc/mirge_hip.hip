@@ -133,10 +133,13 @@ struct Class {
     DevBuf ws_lslots, ws_cnt, ws_cnt0, ws_ctr;
     unsigned long long* h_ctr = nullptr;        // pinned, 4 words
     uint32_t pend_n = 0; int pend_sample = 0; bool pending = false;     // a collapse launched, not yet finished
+    bool pend_part = false; const uint64_t* pend_keys = nullptr; const uint32_t* pend_wt = nullptr;      // ... in partitioned form: its inputs, should it have to start over
+    DevBuf pt_k1, pt_w1, pt_k2, pt_w2, pt_cur;                          // partitioned collapse: level-1 / level-2 regions, cursors + overflow word
     std::vector<Segment> segs;
     void reset() { U = 0; coo_n = 0; gvalid = false; segs.clear(); }
     void release() { ukeys.release(); coo_g.release(); coo_c.release(); gslots.release(); act[0].release(); act[1].release(); fb.release(); ann_round.release(); ann_ref.release(); ann_amb.release();
-                     ws_lslots.release(); ws_cnt.release(); ws_cnt0.release(); ws_ctr.release(); }
+                     ws_lslots.release(); ws_cnt.release(); ws_cnt0.release(); ws_ctr.release();
+                     pt_k1.release(); pt_w1.release(); pt_k2.release(); pt_w2.release(); pt_cur.release(); }
 };
 
 struct KTime { const char* name; hipEvent_t a = nullptr, b = nullptr; bool used = false; double ms = 0; uint64_t bytes = 0; };
@@ -427,15 +430,78 @@ int load_ebwt(mirge_ctx* c, int lib, const std::string& base) {
 // ---- collapse of one key class, in two halves so that the two classes overlap: everything up to the emit kernel is
 // queued on the class's stream by collapse_launch; collapse_finish waits for it, learns how many uniques were new
 // and appends the sample's segment.
+// the partitioned form (kernels.h: k_part_pass / k_part_fold) takes inputs its fixed fan-out suits: from MIRGE_PART_MIN
+// keys (default 2^20: below that the table form's launches are already latency-bound) up to 2^25 (8192 final partitions
+// of <= 4096 records); beyond, and whenever a region overruns, the table form
+bool part_wanted(uint64_t n) {
+    uint64_t lo = 1ull << 20, hi = 176000000ull;
+    if (const char* e = getenv("MIRGE_PART_MIN")) lo = strtoull(e, nullptr, 10);
+    if (const char* e = getenv("MIRGE_PART_MAX")) hi = strtoull(e, nullptr, 10);
+    return n >= lo && n <= hi;
+}
+// fan-out of the first pass: final partitions (P1 x PT_P2 of them, PT_C2 records each at most) should come out about
+// 40 % full when every read is distinct
+int part_p1(uint64_t n) { int p1 = 64; while (p1 < 512 && n > (uint64_t)p1 * 344000ull) p1 *= 2; return p1; }
 template <int KW>
 int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64, int sample, const char* tagA, const char* tagB,
-                    const uint32_t* d_wt = nullptr) {
+                    const uint32_t* d_wt = nullptr, bool allow_part = true) {
     if (n64 >= 0xFFFFFFF0ull) return fail(c, MIRGE_E_LIMIT, "more than 2^32 reads in one collapse call");
     if (C.U + n64 >= 0xFFFFFFF0ull) return fail(c, MIRGE_E_LIMIT, "more than 2^32 unique sequences");
     uint32_t n = (uint32_t)n64;
-    C.pending = true; C.pend_n = n; C.pend_sample = sample;
+    C.pending = true; C.pend_n = n; C.pend_sample = sample; C.pend_part = false; C.pend_keys = d_keys; C.pend_wt = d_wt;
     if (n == 0) return MIRGE_OK;
     hipStream_t st = C.st;
+    if (KW == 2 && allow_part && part_wanted(n)) {
+        const int PT_P1 = part_p1(n);
+        uint32_t C1 = n / PT_P1 + n / (2 * PT_P1) + PT_TILE;                 // 1.5 x the even share
+        if (const char* e = getenv("MIRGE_PART_C1")) C1 = (uint32_t)std::max(1, atoi(e));       // tests: force an overrun
+        const size_t ncur = (size_t)PT_P1 + (size_t)PT_P1 * PT_P2 + 1;
+        HIPCHK(c, C.pt_k1.ensure((size_t)PT_P1 * C1 * 16, false, 0, st));
+        HIPCHK(c, C.pt_w1.ensure((size_t)PT_P1 * C1 * 4, false, 0, st));
+        HIPCHK(c, C.pt_k2.ensure((size_t)PT_P1 * PT_P2 * PT_C2 * 16, false, 0, st));
+        HIPCHK(c, C.pt_w2.ensure((size_t)PT_P1 * PT_P2 * PT_C2 * 4, false, 0, st));
+        HIPCHK(c, C.pt_cur.ensure(ncur * 8, false, 0, st));
+        HIPCHK(c, C.ws_ctr.ensure(64, false, 0, st));
+        HIPCHK(c, C.ukeys.ensure((C.U + n) * KW * 8, true, C.U * KW * 8, st));
+        HIPCHK(c, C.coo_g.ensure((C.coo_n + n) * 4, true, C.coo_n * 4, st));
+        HIPCHK(c, C.coo_c.ensure((C.coo_n + n) * 4, true, C.coo_n * 4, st));
+        const bool use_g = C.U > 0;
+        if (use_g) {
+            uint64_t need = pow2_at_least(2ull * (C.U + n));
+            if (need > (1ull << 32)) need = 1ull << 32;
+            if (!C.gvalid || C.gcap < need) {
+                HIPCHK(c, C.gslots.ensure(need * 4, false, 0, st));
+                C.gcap = need;
+                HIPCHK(c, hipMemsetAsync(C.gslots.p, 0xFF, need * 4, st));
+                hipLaunchKernelGGL((k_gtable_insert<2>), dim3((uint32_t)((C.U + 255) / 256)), dim3(256), 0, st,
+                                   C.ukeys.as<uint64_t>(), 0u, (uint32_t)C.U, C.gslots.as<uint32_t>(), (uint32_t)(C.gcap - 1));
+                C.gvalid = true;
+            }
+        }
+        HIPCHK(c, hipMemsetAsync(C.pt_cur.p, 0, ncur * 8, st));
+        HIPCHK(c, hipMemsetAsync(C.ws_ctr.p, 0, 64, st));
+        unsigned long long* cur = C.pt_cur.as<unsigned long long>();
+        unsigned long long* ovf = cur + ncur - 1;
+        kt_begin(c, "collapse_part16", st);
+        auto pass1 = PT_P1 == 64 ? k_part_pass<64> : PT_P1 == 128 ? k_part_pass<128> : PT_P1 == 256 ? k_part_pass<256> : k_part_pass<512>;
+        hipLaunchKernelGGL(pass1, dim3((n + PT_TILE - 1) / PT_TILE, 1), dim3(PT_BLOCK), 0, st, d_keys, d_wt,
+                           (const unsigned long long*)nullptr, n, 0u, pt_shift1(PT_P1), C.pt_k1.as<uint64_t>(), C.pt_w1.as<uint32_t>(), cur, C1, ovf);
+        hipLaunchKernelGGL((k_part_pass<PT_P2>), dim3((C1 + PT_TILE - 1) / PT_TILE, PT_P1), dim3(PT_BLOCK), 0, st, C.pt_k1.as<uint64_t>(),
+                           C.pt_w1.as<uint32_t>(), (const unsigned long long*)cur, C1, C1, pt_shift2(PT_P1), C.pt_k2.as<uint64_t>(), C.pt_w2.as<uint32_t>(),
+                           cur + PT_P1, (uint32_t)PT_C2, ovf);
+        kt_end(c, "collapse_part16", (uint64_t)n * 16, st);
+        kt_begin(c, "collapse_fold16", st);
+        hipLaunchKernelGGL(k_part_fold, dim3(PT_P1 * PT_P2), dim3(PT_BLOCK), 0, st, C.pt_k2.as<uint64_t>(), C.pt_w2.as<uint32_t>(),
+                           (const unsigned long long*)(cur + PT_P1), use_g ? C.gslots.as<uint32_t>() : (const uint32_t*)nullptr,
+                           (uint32_t)(C.gcap ? C.gcap - 1 : 0), C.ukeys.as<uint64_t>(), (uint32_t)C.U,
+                           C.coo_g.as<uint32_t>() + C.coo_n, C.coo_c.as<uint32_t>() + C.coo_n, C.ws_ctr.as<unsigned long long>());
+        kt_end(c, "collapse_fold16", 0, st);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(C.h_ctr, C.ws_ctr.p, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(C.h_ctr + 2, ovf, 8, hipMemcpyDeviceToHost, st));
+        C.pend_part = true;
+        return MIRGE_OK;
+    }
     uint64_t capL = pow2_at_least((uint64_t)n + n / 4);      // load <= 0.8 even if every read is distinct; smaller table = more of it cache-resident
     if (capL > (1ull << 32)) {                               // slots are addressed by 32 hash bits
         if ((uint64_t)n > 3ull << 30) return fail(c, MIRGE_E_LIMIT, "more than 3 * 2^30 reads in one collapse call");
@@ -496,8 +562,17 @@ int collapse_finish(mirge_ctx* c, Class& C, const char* tagB) {
     C.pending = false;
     if (C.pend_n == 0) { C.segs.push_back({C.pend_sample, C.coo_n, 0}); return MIRGE_OK; }
     HIPCHK(c, hipStreamSynchronize(C.st));
-    uint64_t n_new = C.h_ctr[0] >> 32, n_emit = C.h_ctr[0] & 0xFFFFFFFFull;       // k_collapse_emit packs both into one word
-    ktime(c, tagB).bytes = n_new * (KW * 8 + 4) + n_emit * 4;
+    if (C.pend_part && C.h_ctr[2]) {
+        // a region of the partitioned form overran (skewed hash bits, or more distinct records than its fan-out holds):
+        // nothing it wrote is kept -- the table form takes the same input
+        ktime(c, "collapse_part16").used = false; ktime(c, "collapse_fold16").used = false;
+        int rc = collapse_launch<KW>(c, C, C.pend_keys, C.pend_n, C.pend_sample, "collapse_local16", "collapse_emit16", C.pend_wt, false);
+        C.pending = false;
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(C.st));
+    }
+    uint64_t n_new = C.h_ctr[0] >> 32, n_emit = C.h_ctr[0] & 0xFFFFFFFFull;       // k_collapse_emit / k_part_fold pack both into one word
+    ktime(c, C.pend_part ? "collapse_fold16" : tagB).bytes = n_new * (KW * 8 + 4) + n_emit * 4;
     if (C.gvalid && n_new) {
         hipLaunchKernelGGL((k_gtable_insert<KW>), dim3((uint32_t)((n_new + 255) / 256)), dim3(256), 0, C.st,
                            C.ukeys.as<uint64_t>(), (uint32_t)C.U, (uint32_t)(C.U + n_new), C.gslots.as<uint32_t>(), (uint32_t)(C.gcap - 1));

@@ -55,3 +55,34 @@ def test_more_uniques_than_a_25_bit_hash_can_spread():
         assert ctx.n_unique() == want
         uid, smp, cnt = ctx.export_counts()
         assert len(cnt) == want and int(cnt.sum()) == N
+
+
+@pytest.mark.parametrize("c1", [None, "300"])
+def test_partitioned_collapse_equals_table_form(oracle, monkeypatch, c1):
+    """The partitioned collapse (kernels.h: k_part_pass / k_part_fold; taken from 2^20 keys per call) forced onto a small
+    multi-sample input, against the table form of the same input: same sequences, same per-sample counts; with c1 set,
+    a level-1 region overruns and the call must start over in table form by itself."""
+    import numpy as np
+    from mirge_amd import synth
+    libs, _ = synth.make_libraries(synth.Profile.small(), 77)
+    samples = [synth.make_reads(libs, 120000, 780 + s, zipf_perm_seed=3 + s) for s in range(3)]
+
+    def run():
+        with capi.Context(None, len(samples), 0) as ctx:
+            for s, (seqs, lens) in enumerate(samples):
+                ctx.collapse_seqs(seqs, s, lens)
+            useqs, ulens, _, _, _ = ctx.export_uniques()
+            uid, smp, cnt = ctx.export_counts()
+            names = [useqs[u, :ulens[u]].tobytes() for u in range(len(ulens))]
+            return {(names[int(u)], int(s)): int(c) for u, s, c in zip(uid, smp, cnt)}, ctx.kernel_times()
+
+    monkeypatch.setenv("MIRGE_PART_MIN", "1000000000")
+    want, kt = run()
+    assert "collapse_local16" in kt and "collapse_part16" not in kt
+    monkeypatch.setenv("MIRGE_PART_MIN", "1")
+    if c1:
+        monkeypatch.setenv("MIRGE_PART_C1", c1)
+    got, kt = run()
+    assert ("collapse_local16" in kt) == bool(c1)          # the overrun case ends in table form
+    assert got == want
+    assert sum(got.values()) == sum(len(l) for _, l in samples)
