@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- reads/s through collapse + 5-round library cascade + count vectors on MI355X.
 
-One "step" = one pass of the whole hot path over one batch of synthetic adapter-trimmed reads
-whose 2-bit keys are already resident in HBM: mirge_reset -> mirge_collapse_packed_dev
--> mirge_annotate (cascade + count vectors) [-> one RCCL sum all-reduce of the count vectors when
-N > 1].  Workload at N = 1: BASELINE.json configs[1] -- human-profile synthetic seqLibs, 20M reads.
-For N > 1 every rank gets its own 20M-read shard (weak scaling; independent shards, no data-path
-exchange, only the count-vector all-reduce).
+One "step" = one pass of the whole hot path over one batch of synthetic adapter-trimmed reads whose 2-bit keys are
+already resident in HBM: mirge_reset -> mirge_collapse_packed_dev -> [N > 1: merge of the unique tables
+by key owner, one all-to-all] -> mirge_annotate (cascade + count vectors) -> [N > 1: ONE sum all-reduce of the flat
+count buffer].
+
+Workload.  N = 1: BASELINE.json configs[1] -- human-profile synthetic seqLibs, 20M reads.  N > 1: configs[2] -- ONE read
+set of 100M reads, rank r takes shard_bounds(100M, r, N) (strong scaling: total work fixed; `--weak` gives every rank
+its own 20M-read shard instead).  value = reads of the whole job / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -22,22 +26,115 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+REF_PUBLISHED_READS_PER_S = 92000   # the reference's only published run: 1,436,249 trimmed reads through the cascade in 15.55 s
+
+
+def gen_keys(torch, synth, capi, ctx, libs, lo, hi, chunk, mix, W, rank, keep_first=0, e2e_reads=0, label="reads"):
+    """Reads [lo, hi) of the run's read set (chunk c of it = make_reads(seed BASE + 1000 + c): the same on every rank)
+    -> ASCII matrix in HBM -> 2-bit keys in HBM.  Returns (k16, n16, k48, n48, first reads kept on the host, e2e parts, bytes)."""
+    n = hi - lo
+    k16 = torch.empty((max(n, 1), 2), dtype=torch.int64, device="cuda")
+    t16 = torch.empty((chunk, 2), dtype=torch.int64, device="cuda")
+    t48 = torch.empty((chunk, 6), dtype=torch.int64, device="cuda")
+    k48_parts, n16, h2d, first, e2e = [], 0, 0, None, []
+    done = 0
+    for c in range(lo // chunk, (hi + chunk - 1) // chunk):
+        seqs, lens = synth.make_reads(libs, chunk, synth.BASE_SEED + 1000 + c, mix, W=W)
+        a, b = max(lo, c * chunk) - c * chunk, min(hi, (c + 1) * chunk) - c * chunk
+        seqs, lens = seqs[a:b], lens[a:b]
+        m = len(lens)
+        if first is None and keep_first:
+            first = (seqs[:keep_first].copy(), lens[:keep_first].copy())
+        if done < e2e_reads:
+            e2e.append((seqs[:e2e_reads - done], lens[:e2e_reads - done]))
+        d_seqs = torch.from_numpy(np.ascontiguousarray(seqs)).cuda(); d_lens = torch.from_numpy(np.ascontiguousarray(lens)).cuda()
+        h2d += seqs.nbytes + lens.nbytes
+        torch.cuda.synchronize()
+        x, w = ctx.pack_dev(d_seqs.data_ptr(), W, d_lens.data_ptr(), m, t16.data_ptr(), t48.data_ptr())
+        k16[n16:n16 + x].copy_(t16[:x]); n16 += x
+        if w:
+            k48_parts.append(t48[:w].clone())
+        torch.cuda.synchronize()
+        done += m
+        if rank == 0 and (done // chunk) % 20 == 0:
+            print("[bench] %d / %d %s generated and packed" % (done, n, label), file=sys.stderr, flush=True)
+    k48 = torch.cat(k48_parts) if k48_parts else torch.empty((1, 6), dtype=torch.int64, device="cuda")
+    return k16, n16, k48, n - n16, first, e2e, h2d
+
+
+def tool_version(exe):
+    p = shutil.which(exe)
+    if not p:
+        return None
+    try:
+        out = subprocess.run([p, "--version"], capture_output=True, text=True, timeout=20).stdout
+        return (p, out.strip().split("\n")[0])
+    except Exception:
+        return (p, "?")
+
+
+def reference_cpu_leg(synth, libs, seqs, lens, cores):
+    """BASELINE.md step 1 / SURVEY.md 8d: if bowtie (1.x) is on PATH, time the reference's own five command lines
+    (miRge.pl:333-339) on the sample, index built once with bowtie-build.  Returns a cpu_baseline dict or None."""
+    bt = tool_version("bowtie"); btb = shutil.which("bowtie-build")
+    if not bt or not btb:
+        return None
+    import tempfile
+    from collections import Counter
+    d = tempfile.mkdtemp(prefix="mirge_ref_")
+    try:
+        for nm in synth.LIB_NAMES:
+            fa = os.path.join(d, nm + ".fa")
+            with open(fa, "w") as f:
+                L = libs[nm]
+                for i, name in enumerate(L.names):
+                    f.write(">%s\n%s\n" % (name, L.text[L.offs[i]:L.offs[i + 1]].tobytes().decode()))
+            subprocess.run([btb, "-q", fa, os.path.join(d, nm)], check=True, capture_output=True, timeout=3600)
+        reads = synth.reads_to_list(seqs, lens)
+        t0 = time.perf_counter()
+        todo = list(Counter(reads))                          # quantReads: the hash keys
+        rounds = [("mirna", lambda s: len(s) < 26, ["-n", "0"]), ("hairpin", lambda s: len(s) > 25, ["-n", "1"]),
+                  ("other", lambda s: True, ["-n", "1"]), ("mrna", lambda s: True, ["-n", "0"]),
+                  ("mirna", lambda s: True, ["-l", "15", "-5", "1", "-3", "2", "-n", "2"])]
+        for lib, ok, opts in rounds:
+            fa = os.path.join(d, "SeqToAnnot.fasta")
+            with open(fa, "w") as f:
+                for s in todo:
+                    if ok(s):
+                        f.write(">%s\n%s\n" % (s, s))
+            out = subprocess.run([bt[0], "-a", "--best", "--strata", "--threads", str(cores), os.path.join(d, lib)] + opts + ["-f", fa],
+                                 capture_output=True, text=True, timeout=3600, check=True).stdout
+            hit = {line.split("\t", 1)[0] for line in out.split("\n") if line}
+            todo = [s for s in todo if s not in hit]
+        dt = time.perf_counter() - t0
+        return {"value": len(lens) / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
+                "sample": "first %d reads of the same workload: Perl-style collapse + the five bowtie command lines of miRge.pl:333-339 "
+                          "(%s, --threads %d), indexes built once with bowtie-build (not timed); %.1f s" % (len(lens), bt[1], cores, dt)}
+    except Exception as e:                                    # a tool that is there but does not run: say so, keep the port
+        print("[bench] reference CPU leg failed: %r" % (e,), file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=20_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=20_000_000, help="reads per GPU (N = 1, and N > 1 with --weak)")
+    ap.add_argument("--total-reads", type=int, default=100_000_000, help="N > 1: reads of the one read set the ranks share")
+    ap.add_argument("--weak", action="store_true", help="N > 1: independent --reads-sized shards per rank instead of one shared read set")
+    ap.add_argument("--no-merge-uniques", action="store_true",
+                    help="N > 1: skip the all-to-all of the unique tables by key owner (count vectors stay exact; trimmed_uniq, "
+                         "annotStats and the per-unique tables then count a sequence once per shard that holds it)")
     ap.add_argument("--profile", default="human", choices=["human", "mouse", "medium", "small", "tiny"])
-    ap.add_argument("--mixture", default="default", choices=["default", "isomir_rich"])
-    ap.add_argument("--cpu-sample", type=int, default=100_000, help="reads of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--mixture", default="default", choices=["default", "isomir_rich", "realistic"])
+    ap.add_argument("--cpu-sample", type=int, default=300_000, help="reads of the same workload timed on the CPU (0 = skip)")
     ap.add_argument("--chunk", type=int, default=1_000_000)
-    ap.add_argument("--merge-uniques", action="store_true",
-                    help="N > 1: all-to-all of the unique tables by key owner between collapse and cascade (exact trimmed_uniq / "
-                         "per-round unique counts; off by default: the shards of this synthetic workload are independent)")
-    ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end leg: FASTQ file -> count vectors (0 = skip)")
+    ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end legs: FASTQ file -> count vectors (0 = skip)")
+    ap.add_argument("--realistic-reads", type=int, default=20_000_000, help="reads of the extra line at the reference's published redundancy (0 = skip)")
+    ap.add_argument("--perl-reads", type=int, default=1_000_000, help="raw reads of the e2e_perl leg, BASELINE.json configs[0] (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -46,61 +143,44 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal on a one-GPU box only: MIRGE_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and swaps RCCL (which refuses two
-    # ranks on one device) for gloo, so the N > 1 code path can be run where there is a single card
+    # ranks on one device) for gloo (the all-to-all of merge_uniques is then staged through host tensors)
     rehearsal = os.environ.get("MIRGE_BENCH_ONE_DEVICE") == "1"
     if rehearsal:
         local = 0
-        if args.merge_uniques:
-            sys.exit("MIRGE_BENCH_ONE_DEVICE rehearses the all-reduce path only: gloo has no all-to-all over device buffers")
     torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=dev)
+    merge = world > 1 and not args.no_merge_uniques
+    solo = rank == 0 and world == 1
 
     prof = getattr(synth.Profile, args.profile)()
-    mix = synth.Mixture.default() if args.mixture == "default" else synth.Mixture.isomir_rich()
-    libs, _ = synth.make_libraries(prof, synth.BASE_SEED)
+    mix = getattr(synth.Mixture, args.mixture)()
+    libs, merges = synth.make_libraries(prof, synth.BASE_SEED)
     ctx = capi.Context(None, 1, local)
     t0 = time.perf_counter()
     for i, nm in enumerate(synth.LIB_NAMES):
         ctx.load_library(i, libs[nm].names, libs[nm].text, libs[nm].offs)
     t_index = time.perf_counter() - t0
 
-    # ---- synthetic reads of this rank's shard -> ASCII matrix in HBM -> 2-bit keys in HBM
-    N = args.reads
+    # ---- this rank's reads
     W = 48
-    k16 = torch.empty((N, 2), dtype=torch.int64, device="cuda")
-    k48_parts = []
-    n16 = 0
-    sample_seqs = sample_lens = None
-    e2e_parts = []
-    t16 = torch.empty((args.chunk, 2), dtype=torch.int64, device="cuda")
-    t48 = torch.empty((args.chunk, 6), dtype=torch.int64, device="cuda")
-    h2d_bytes = 0
-    for c, b in enumerate(range(0, N, args.chunk)):
-        m = min(args.chunk, N - b)
-        seqs, lens = synth.make_reads(libs, m, synth.BASE_SEED + 1000 * (rank + 1) + c, mix, W=W)
-        if c == 0:
-            sample_seqs, sample_lens = seqs[:args.cpu_sample].copy(), lens[:args.cpu_sample].copy()
-        if rank == 0 and world == 1 and b < args.e2e_reads:
-            e2e_parts.append((seqs[:args.e2e_reads - b], lens[:args.e2e_reads - b]))
-        d_seqs = torch.from_numpy(seqs).cuda(); d_lens = torch.from_numpy(lens).cuda()
-        h2d_bytes += seqs.nbytes + lens.nbytes
-        torch.cuda.synchronize()
-        a, w = ctx.pack_dev(d_seqs.data_ptr(), W, d_lens.data_ptr(), m, t16.data_ptr(), t48.data_ptr())
-        k16[n16:n16 + a].copy_(t16[:a]); n16 += a
-        if w:
-            k48_parts.append(t48[:w].clone())
-        torch.cuda.synchronize()
-        if rank == 0 and c % 20 == 19:
-            print("[bench] %d / %d reads generated and packed" % (b + m, N), file=sys.stderr, flush=True)
-    k48 = torch.cat(k48_parts) if k48_parts else torch.empty((1, 6), dtype=torch.int64, device="cuda")
-    n48 = N - n16
-    del t16, t48, k48_parts
+    if world == 1:
+        total, lo, hi = args.reads, 0, args.reads
+    elif args.weak:
+        total, lo, hi = args.reads * world, rank * args.reads, (rank + 1) * args.reads
+    else:
+        total = args.total_reads
+        lo, hi = shard.shard_bounds(total, rank, world)
+    N = hi - lo
+    k16, n16, k48, n48, first, e2e_parts, h2d_bytes = gen_keys(torch, synth, capi, ctx, libs, lo, hi, args.chunk, mix, W, rank,
+                                                               keep_first=args.cpu_sample if solo else 0,
+                                                               e2e_reads=max(args.e2e_reads, args.perl_reads) if solo else 0)
     torch.cuda.synchronize()
 
     # measured device copy bandwidth of this GPU in this run (report against it as well as the 8 TB/s spec)
@@ -114,17 +194,14 @@ def main():
     copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del src, dst
 
-    flat_dev = None
-
-    def step():
-        nonlocal flat_dev
-        ctx.reset()
-        ctx.collapse_packed_dev(k16.data_ptr(), n16, k48.data_ptr(), n48, 0)
-        if world > 1 and args.merge_uniques:
-            shard.merge_uniques(ctx, dist, torch.device("cuda", local))
-        ctx.annotate()
+    def step(c=ctx, a=k16, na=n16, b=k48, nb=n48):
+        c.reset()
+        c.collapse_packed_dev(a.data_ptr(), na, b.data_ptr(), nb, 0)
+        if merge:
+            shard.merge_uniques(c, dist, dev)
+        c.annotate()
         if world > 1:
-            ctx.set_counts_flat(shard.allreduce_flat(ctx.counts_flat(), dist, torch.device("cuda", local)))
+            shard.allreduce_counts(c, dist, dev)
 
     def fence():
         torch.cuda.synchronize()
@@ -132,35 +209,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n_steps, **kw):
+        fence()
+        t0 = time.perf_counter()
+        dev_ms, kts = [], []
+        for _ in range(n_steps):
+            step(**kw)
+            tm = ctx.last_timing(); dev_ms.append(tm["collapse_ms"] + tm["annotate_ms"] + tm["counts_ms"])
+            kts.append(ctx.kernel_times())
+        fence()
+        return time.perf_counter() - t0, dev_ms, kts
+
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    dev_ms = []
-    ktimes = []
-    for _ in range(args.steps):
-        step()
-        tm = ctx.last_timing(); dev_ms.append(tm["collapse_ms"] + tm["annotate_ms"] + tm["counts_ms"])
-        ktimes.append(ctx.kernel_times())
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, dev_ms, ktimes = timed(args.steps)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if not rehearsal else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     # ---- algorithmic bytes: B = 16N [+4N uid, not written here] + 20U + 4nnz + sum_r 20 U_r + sum_r |lib_r|/4 + 16 M S
-    U = ctx.n_unique(); nnz = U
+    # (after merge + all-reduce U and the round statistics are those of the whole job)
     stats = [ctx.round_stats(r + 1) for r in range(5)]
+    if merge:
+        ut = torch.tensor([ctx.n_unique()], dtype=torch.int64, device="cuda" if not rehearsal else "cpu")
+        dist.all_reduce(ut)
+        U = int(ut.item())
+    else:
+        U = ctx.n_unique()
+    nnz = U
     libT = [len(libs[nm].text) + libs[nm].n for nm in synth.LIB_NAMES]
     round_lib = [0, 1, 2, 3, 0]
     M = libs["mirna"].n
-    b_alg = 16 * N + 20 * U + 4 * nnz + sum(20 * s[0] for s in stats) + sum(libT[l] // 4 for l in round_lib) + 16 * M
-    # per-kernel: average duration over the timed steps, algorithmic bytes as the library reports them
-    names = list(ktimes[-1].keys())
-    kavg = {k: (float(np.mean([kt[k][0] for kt in ktimes if k in kt])), int(ktimes[-1][k][1])) for k in names if k != "pack"}
+    n_job = total if (world == 1 or merge) else N
+    b_alg = 16 * n_job + 20 * U + 4 * nnz + sum(20 * s[0] for s in stats) + sum(libT[l] // 4 for l in round_lib) + 16 * M
+    # per kernel: average / median duration over the timed steps, algorithmic bytes as the library reports them
+    names = [k for k in ktimes[-1].keys() if k != "pack"]
+    kavg = {k: (float(np.mean([kt[k][0] for kt in ktimes if k in kt])), int(ktimes[-1][k][1]),
+                float(np.median([kt[k][0] for kt in ktimes if k in kt]))) for k in names}
     dom = max(kavg, key=lambda k: kavg[k][0])
-    dom_ms, dom_bytes = kavg[dom]
+    dom_ms, dom_bytes, _ = kavg[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -171,96 +259,184 @@ def main():
                 traffic = tj.get("kernels", {}).get(dom)
         except Exception:
             traffic = None
-    dev_ms_avg = float(np.mean(dev_ms))
+    dev_ms_avg, dev_ms_med = float(np.mean(dev_ms)), float(np.median(dev_ms))
 
+    if world == 1:
+        workload = ("BASELINE.json configs[1]: %s-profile synthetic seqLibs, %d adapter-trimmed reads on one GPU, 5-round cascade "
+                    "(exact miRNA, hairpin 1mm, other 1mm, mRNA, isomiR 2mm)" % (args.profile, N))
+    elif args.weak:
+        workload = "weak scaling: %s-profile synthetic seqLibs, an independent %d-read shard per GPU, 5-round cascade" % (args.profile, args.reads)
+    else:
+        workload = ("BASELINE.json configs[2]: %s-profile synthetic seqLibs, ONE set of %d adapter-trimmed reads sharded over %d GPUs "
+                    "(contiguous chunks), 5-round cascade, RCCL count all-reduce" % (args.profile, total, world))
     out = {
         "metric": "reads/sec annotated (collapse+library cascade)",
-        "value": world * N * args.steps / elapsed,
+        "value": (N * world if (world > 1 and args.weak) else total) * args.steps / elapsed,
         "unit": "reads/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak" if (world == 1 or args.weak) else "strong", "vs_baseline": None,
         "dtype": "u64 (2-bit packed nucleotides, integer XOR/popcount)", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: %s-profile synthetic seqLibs, %d adapter-trimmed reads per GPU, "
-                               "5-round cascade (exact miRNA, hairpin 1mm, other 1mm, mRNA, isomiR 2mm)" % (args.profile, N),
-                   "reads_per_gpu": N, "uniques": int(U), "samples": 1, "mixture": args.mixture,
+        "config": {"workload": workload, "reads_total": int(N * world if (world > 1 and args.weak) else total), "reads_this_rank": int(N),
+                   "uniques": int(U), "samples": 1, "mixture": args.mixture,
                    "lib_nt": {nm: int(len(libs[nm].text)) for nm in synth.LIB_NAMES},
                    "round_uniques": [int(s[0]) for s in stats], "round_aligned": [int(s[1]) for s in stats],
-                   "parallelism": "shard%d%s" % (world, "+merge_uniques" if (world > 1 and args.merge_uniques) else "")},
+                   "parallelism": "shard%d%s%s" % (world, "+merge_uniques" if merge else "", "+gloo_one_device_rehearsal" if rehearsal and world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "copy_measured": copy_gbs, "frac_of_copy": achieved / copy_gbs,
-                     "kernel_ms": dom_ms, "kernel_bytes_alg": dom_bytes},
-        "roofline_path": {"bytes_alg_per_read": b_alg / N, "device_ms": dev_ms_avg,
-                          "achieved": b_alg / (dev_ms_avg * 1e-3) / 1e9 if dev_ms_avg > 0 else 0.0,
-                          "frac": (b_alg / (dev_ms_avg * 1e-3) / 1e9) / HBM_PEAK_GBS if dev_ms_avg > 0 else 0.0},
+                     "kernel_ms": dom_ms, "kernel_bytes_alg": dom_bytes,
+                     "note": "achieved = SURVEY.md 8d's algorithmic bytes of the kernel / its HIP-event time: an index-based matcher cannot "
+                             "reach that floor.  What bounds the kernel on the machine is the rate of random 128-B line fetches past the L2 "
+                             "(`traffic`, PMC) and vector issue, not streaming HBM bandwidth -- DESIGN.md section 4"},
+        "roofline_path": {"bytes_alg_per_read": b_alg / n_job, "device_ms": dev_ms_avg, "device_ms_median": dev_ms_med,
+                          "achieved": b_alg / world / (dev_ms_avg * 1e-3) / 1e9 if dev_ms_avg > 0 else 0.0,
+                          "frac": (b_alg / world / (dev_ms_avg * 1e-3) / 1e9) / HBM_PEAK_GBS if dev_ms_avg > 0 else 0.0},
         "kernels_ms": {k: round(v[0], 4) for k, v in kavg.items()},
+        "kernels_ms_median": {k: round(v[2], 4) for k, v in kavg.items()},
         "setup": {"index_build_s": round(t_index, 3), "h2d_bytes": int(h2d_bytes)},
     }
 
-    # ---- CPU baseline: the oracle (a port; the reference's bowtie/cutadapt are not installed) on a bounded sample
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    # ---- how much of the assignment rides on the tie-order hypothesis H1: uniques / reads whose best stratum held > 1 reference
+    if solo:
+        _, _, rnd_, _, amb_ = ctx.export_uniques(with_seqs=False)
+        uid_, _, cnt_ = ctx.export_counts()
+        per = np.zeros(len(rnd_), dtype=np.int64); np.add.at(per, uid_.astype(np.int64), cnt_.astype(np.int64))
+        ann = rnd_ > 0
+        out["h1_dependent"] = {"uniques_annotated": int(ann.sum()), "uniques_ambiguous": int((ann & (amb_ > 0)).sum()),
+                               "reads_annotated": int(per[ann].sum()), "reads_ambiguous": int(per[ann & (amb_ > 0)].sum()),
+                               "note": "ambiguous = the best stratum held more than one reference, so which one miRge keeps follows hypothesis H1 "
+                                       "(parity with bowtie 1.1.1 unpinned)"}
+
+    # ---- CPU baseline on a bounded sample: the reference's own tools when the box has them, else the oracle (a port)
+    if solo and args.cpu_sample > 0 and first is not None:
         from oracle import oracle as orc
         cores = min(16, os.cpu_count() or 1)
+        sample_seqs, sample_lens = first
+        ref = reference_cpu_leg(synth, libs, sample_seqs, sample_lens, cores)
         olibs = [orc.OracleLib((libs[nm].text, libs[nm].offs)) for nm in synth.LIB_NAMES]   # index build: not timed
         t0 = time.perf_counter()
         res = orc.run_path(olibs, [(sample_seqs, sample_lens)], use_index=True, nthreads=cores, maxlen=capi.MAX_READ_LEN)
         dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": len(sample_lens) / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-                               "sample": "first %d reads of the same workload, same libraries; collapse + 5-round cascade + "
-                                         "count vectors by oracle/mirge_oracle.c (k-mer-indexed matcher, OpenMP over uniques); "
-                                         "index build excluded; %.1f s" % (len(sample_lens), dt)}
-        # and the GPU path must agree with it on that sample
+        port = {"value": len(sample_lens) / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+                "sample": "first %d reads of the same workload, same libraries; collapse + 5-round cascade + count vectors by "
+                          "oracle/mirge_oracle.c (k-mer-indexed matcher, OpenMP over uniques); index build excluded; %.1f s"
+                          % (len(sample_lens), dt)}
+        out["cpu_baseline"] = ref or port
+        out["cpu_baseline"]["reference_published"] = {"value": REF_PUBLISHED_READS_PER_S, "unit": "reads/s",
+                                                      "note": "miRge's own example run (cascade only, hardware and threads not stated): report.html:170-175"}
+        out["cpu_baseline"]["tools_found"] = {t: tool_version(t) for t in ("bowtie", "bowtie-build", "cutadapt")}
+        if ref:
+            out["cpu_baseline_port"] = port
+        # and the GPU path must agree with the checker on that sample
         ctx.reset()
         ctx.collapse_seqs(sample_seqs, 0, sample_lens)
         ctx.annotate()
         cv = ctx.counts()
         ok = all(np.array_equal(cv[k], res[k]) for k in ("quant", "iscan", "cat", "tuniq", "lenhist"))
         out["parity_on_cpu_sample"] = bool(ok)
-    # ---- end-to-end leg (reported separately, never `value`): trimmed FASTQ file (page cache) -> HBM ->
-    #      record splitting + packing on the device -> collapse -> cascade -> count vectors on the host
-    if rank == 0 and world == 1 and e2e_parts:
+
+    # ---- the same path at the redundancy of the reference's published run (U/N ~ 0.13): an extra line, never `value`
+    if solo and args.realistic_reads > 0 and args.mixture != "realistic":
+        rk16, rn16, rk48, rn48, _, _, _ = gen_keys(torch, synth, capi, ctx, libs, 0, args.realistic_reads, args.chunk,
+                                                   synth.Mixture.realistic(), W, rank, label="reads (realistic mixture)")
+        kw = dict(a=rk16, na=rn16, b=rk48, nb=rn48)
+        step(**kw); step(**kw)
+        el, dms, kts = timed(max(3, args.steps // 2), **kw)
+        nst = max(3, args.steps // 2)
+        rs = [ctx.round_stats(r + 1) for r in range(5)]
+        out["realistic"] = {"reads": int(args.realistic_reads), "uniques": int(ctx.n_unique()), "unique_fraction": ctx.n_unique() / args.realistic_reads,
+                            "reads_per_s": args.realistic_reads * nst / el, "ms_per_step": 1e3 * el / nst,
+                            "kernels_ms": {k: round(float(np.mean([kt[k][0] for kt in kts if k in kt])), 4) for k in kts[-1] if k != "pack"},
+                            "round_uniques": [int(s[0]) for s in rs], "round_aligned": [int(s[1]) for s in rs],
+                            "note": "class proportions and redundancy of docs/miRge/miRge.exampleOutput/report.html:159-175 (synth.Mixture.realistic)"}
+        del rk16, rk48
+
+    # ---- end-to-end legs (reported separately, never `value`)
+    if solo and e2e_parts:
         import tempfile
-        path = os.path.join(tempfile.gettempdir(), "mirge_bench_%d.fastq" % os.getpid())
         es = np.concatenate([p[0] for p in e2e_parts]); el = np.concatenate([p[1] for p in e2e_parts])
-        nbytes = synth.write_fastq_fast(path, es, el)
-        best = None
-        for _ in range(3):
-            ctx.reset()
-            t0 = time.perf_counter()
-            nr = ctx.collapse_fastq(path, 0)
-            t1 = time.perf_counter()
-            ctx.annotate(); ctx.counts()
-            t2 = time.perf_counter()
-            kt = ctx.kernel_times()
-            cur = {"reads": int(nr), "fastq_bytes": int(nbytes), "seconds": t2 - t0, "reads_per_s": nr / (t2 - t0),
-                   "file_to_keys_s": t1 - t0, "file_GBps": nbytes / (t1 - t0) / 1e9,
-                   "fastq_kernels_ms": {k: round(v[0], 4) for k, v in kt.items() if k.startswith("fastq")},
-                   "note": "file in the page cache; reader threads -> pinned ring -> DMA -> k_fq_count/index/pack -> collapse -> "
-                           "cascade -> counts; best of 3"}
-            if best is None or cur["seconds"] < best["seconds"]:
-                best = cur
-        os.unlink(path)
-        assert nr == len(el)
-        out["e2e"] = best
-        # the same from RAW reads: 50-nt reads with the 3' adapter still on, trimming on the device
-        nbytes = synth.write_raw_fastq_fast(path, es, el, synth.BASE_SEED + 77)
-        best = None
-        for _ in range(3):
-            ctx.reset()
-            t0 = time.perf_counter()
-            tot, kept, _ = ctx.collapse_raw_fastq(path, 0, "illumina")
-            t1 = time.perf_counter()
-            ctx.annotate(); ctx.counts()
-            t2 = time.perf_counter()
-            kt = ctx.kernel_times()
-            cur = {"reads": int(tot), "kept": int(kept), "fastq_bytes": int(nbytes), "seconds": t2 - t0, "reads_per_s": tot / (t2 - t0),
-                   "file_to_keys_s": t1 - t0, "fastq_kernels_ms": {k: round(v[0], 4) for k, v in kt.items() if k.startswith("fastq")},
-                   "note": "raw 50-nt reads, adapter on: quality trim + adapter alignment + length filter on the device, then as e2e; best of 3"}
-            if best is None or cur["seconds"] < best["seconds"]:
-                best = cur
-        os.unlink(path)
-        out["e2e_raw"] = best
+        tmpd = tempfile.mkdtemp(prefix="mirge_bench_")
+        path = os.path.join(tmpd, "s.fastq")
+        if args.e2e_reads > 0:
+            ne = min(args.e2e_reads, len(el))
+            # trimmed FASTQ file (page cache) -> HBM -> record splitting + packing on the device -> collapse -> cascade -> count vectors
+            nbytes = synth.write_fastq_fast(path, es[:ne], el[:ne])
+            best = None
+            for _ in range(3):
+                ctx.reset()
+                t0 = time.perf_counter()
+                nr = ctx.collapse_fastq(path, 0)
+                t1 = time.perf_counter()
+                ctx.annotate(); ctx.counts()
+                t2 = time.perf_counter()
+                kt = ctx.kernel_times()
+                cur = {"reads": int(nr), "fastq_bytes": int(nbytes), "seconds": t2 - t0, "reads_per_s": nr / (t2 - t0),
+                       "file_to_keys_s": t1 - t0, "file_GBps": nbytes / (t1 - t0) / 1e9,
+                       "fastq_kernels_ms": {k: round(v[0], 4) for k, v in kt.items() if k.startswith("fastq")},
+                       "note": "file in the page cache; reader threads -> pinned ring -> DMA -> k_fq_count/index/pack -> collapse -> "
+                               "cascade -> counts; best of 3"}
+                if best is None or cur["seconds"] < best["seconds"]:
+                    best = cur
+            assert nr == ne
+            out["e2e"] = best
+            # the same from RAW reads: 50-nt reads with the 3' adapter still on, trimming on the device
+            nbytes = synth.write_raw_fastq_fast(path, es[:ne], el[:ne], synth.BASE_SEED + 77)
+            best = None
+            for _ in range(3):
+                ctx.reset()
+                t0 = time.perf_counter()
+                tot, kept, _ = ctx.collapse_raw_fastq(path, 0, "illumina")
+                t1 = time.perf_counter()
+                ctx.annotate(); ctx.counts()
+                t2 = time.perf_counter()
+                kt = ctx.kernel_times()
+                cur = {"reads": int(tot), "kept": int(kept), "fastq_bytes": int(nbytes), "seconds": t2 - t0, "reads_per_s": tot / (t2 - t0),
+                       "file_to_keys_s": t1 - t0, "fastq_kernels_ms": {k: round(v[0], 4) for k, v in kt.items() if k.startswith("fastq")},
+                       "note": "raw 50-nt reads, adapter on: quality trim + adapter alignment + length filter on the device, then as e2e; best of 3"}
+                if best is None or cur["seconds"] < best["seconds"]:
+                    best = cur
+            out["e2e_raw"] = best
+        # BASELINE.json configs[0] through the drop-in's own hosts: raw reads with adapter -> tables on disk, wall clock, each in
+        # a process of its own (library load + index build included, as a user pays them)
+        if args.perl_reads > 0:
+            npl = min(args.perl_reads, len(el))
+            synth.write_raw_fastq_fast(path, es[:npl], el[:npl], synth.BASE_SEED + 78)
+            sp = os.path.join(tmpd, "species")
+            synth.write_species_dir(sp, libs, merges)
+            leg = {"reads": int(npl), "note": "BASELINE.json configs[0]: raw 50-nt reads with adapter, FASTQ file -> trimming + collapse + cascade on "
+                                              "the device -> mapped/unmapped/miR.Counts/miR.RPM tables on disk; wall clock of a fresh process each"}
+            env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", "0"))
+            ann = os.path.join(ROOT, "tools", "mirge-annotate")
+            if os.path.exists(ann):
+                od = os.path.join(tmpd, "out_native")
+                t0 = time.perf_counter()
+                r = subprocess.run([ann, "--species", sp, "--SampleFiles", path, "--SampleNames", "s", "--adapter", "illumina", "--outputDir", od],
+                                   capture_output=True, text=True, env=env, timeout=600)
+                leg["native_seconds"] = time.perf_counter() - t0
+                leg["native_ok"] = r.returncode == 0 and os.path.exists(os.path.join(od, "miR.Counts.csv"))
+                if r.returncode:
+                    leg["native_error"] = (r.stderr or r.stdout)[-300:]
+            pl = os.path.join(ROOT, "perl", "t", "hotpath.pl")
+            if os.path.exists(pl) and shutil.which("perl") and os.path.exists(os.path.join(ROOT, "perl", "auto", "MirgeHip", "MirgeHip.so")):
+                od = os.path.join(tmpd, "out_perl")
+                t0 = time.perf_counter()
+                r = subprocess.run(["perl", "-I" + os.path.join(ROOT, "perl"), pl, "--species", sp, "--out", od, "--adapter", "illumina",
+                                    "--names", "s", path], capture_output=True, text=True, env=env, timeout=900)
+                leg["perl_seconds"] = time.perf_counter() - t0
+                leg["perl_ok"] = r.returncode == 0 and os.path.exists(os.path.join(od, "miR.Counts.csv"))
+                if r.returncode:
+                    leg["perl_error"] = (r.stderr or r.stdout)[-300:]
+                for line in (r.stderr or "").split("\n"):            # the script's own stage times
+                    if line.startswith("[hotpath]"):
+                        leg.setdefault("perl_stages", []).append(line[len("[hotpath] "):])
+                if leg.get("native_ok") and leg.get("perl_ok"):
+                    leg["tables_identical"] = all(
+                        open(os.path.join(tmpd, "out_native", f)).read() == open(os.path.join(tmpd, "out_perl", f)).read()
+                        for f in ("miR.Counts.csv", "miR.RPM.csv"))
+            out["e2e_perl"] = leg
+        shutil.rmtree(tmpd, ignore_errors=True)
+
     # size-independent invariants of the full-size run (every read lands in exactly one category / length bin)
     if world == 1:
         print("[bench] timed steps done; full-size invariants", file=sys.stderr, flush=True)
@@ -269,10 +445,15 @@ def main():
         ctx.annotate()
         cvf = ctx.counts()
         uid, smp, cnt = ctx.export_counts()
+        st2 = [ctx.round_stats(r + 1) for r in range(5)]
         out["invariants_full_size"] = bool(int(cvf["cat"].sum()) == N and int(cvf["lenhist"].sum()) == N and
                                            int(cnt.sum()) == N and int(cvf["tuniq"][0]) == len(cnt) == ctx.n_unique() and
                                            int(cvf["quant"].sum()) == int(cvf["cat"][0].sum()) and
-                                           sum(s[1] for s in stats) + int((ctx.export_uniques(with_seqs=False)[2] == 0).sum()) == ctx.n_unique())
+                                           sum(s[1] for s in st2) + int((ctx.export_uniques(with_seqs=False)[2] == 0).sum()) == ctx.n_unique())
+    elif rank == 0 and merge:
+        # after merge + all-reduce every read of the whole job sits in exactly one category on every rank's copy of the sums
+        cvf = ctx.counts()
+        out["invariants_full_size"] = bool(int(cvf["cat"].sum()) == total and int(cvf["lenhist"].sum()) == total and int(cvf["tuniq"][0]) == U)
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

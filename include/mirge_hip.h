@@ -162,12 +162,16 @@ int32_t     mirge_round_stats(const mirge_ctx*, int32_t round, uint64_t* process
  * only round 1 (if it is one of them) to iscan -- which is miRge.pl:469-489 for the reference's own five rounds. */
 int32_t     mirge_counts(mirge_ctx*, const uint64_t** quant, const uint64_t** iscan, const uint64_t** category,
                          const uint64_t** len_hist, const uint64_t** trimmed_uniq);
-/* Multi-GPU: the count vectors of this context as one flat uint64 buffer
- * [quant | iscan | category | len_hist | trimmed_uniq], for a single sum
- * all-reduce across ranks, and the setter that installs the reduced result. */
+/* Multi-GPU (the reference is one process): everything this context counted as one flat uint64 buffer
+ * [quant | iscan | category | len_hist | trimmed_uniq | readsProcessed[MIRGE_MAX_ROUNDS] | readsAligned[MIRGE_MAX_ROUNDS]]
+ * (annotStats of miRge.pl:410-413 included), for a single sum all-reduce across ranks, and the setter that installs
+ * the reduced result (mirge_counts / mirge_round_stats then return the sums).  The _dev forms leave / take the buffer
+ * in device memory (mirge_counts_flat_len() words), so that RCCL reduces it where it lies. */
 uint64_t    mirge_counts_flat_len(const mirge_ctx*);
 int32_t     mirge_counts_flat_get(mirge_ctx*, uint64_t* out);
 int32_t     mirge_counts_flat_set(mirge_ctx*, const uint64_t* in);
+int32_t     mirge_counts_flat_get_dev(mirge_ctx*, void* d_out);
+int32_t     mirge_counts_flat_set_dev(mirge_ctx*, const void* d_in);
 
 /* Multi-GPU exchange step (no counterpart in the single-process reference).  After the local
  * collapse, every rank sends each (unique, sample, count) entry to the rank that owns its sequence (a hash of

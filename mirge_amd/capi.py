@@ -25,7 +25,7 @@ EXPORTS = [
     "mirge_shard_export_sizes", "mirge_shard_export", "mirge_shard_import",
     "mirge_collapse_fastq", "mirge_collapse_fastq_mem", "mirge_collapse_fastq_dev", "mirge_collapse_seqs", "mirge_collapse_ascii_dev", "mirge_pack_dev",
     "mirge_collapse_packed_dev", "mirge_annotate", "mirge_round_stats", "mirge_counts", "mirge_counts_flat_len",
-    "mirge_counts_flat_get", "mirge_counts_flat_set", "mirge_n_unique", "mirge_unique", "mirge_export_uniques",
+    "mirge_counts_flat_get", "mirge_counts_flat_set", "mirge_counts_flat_get_dev", "mirge_counts_flat_set_dev", "mirge_n_unique", "mirge_unique", "mirge_export_uniques",
     "mirge_n_counts", "mirge_export_counts", "mirge_last_timing", "mirge_kernel_times", "mirge_write_tables",
     "mirge_collapse_keys16_noalloc",
 ]
@@ -94,6 +94,8 @@ def load():
     L.mirge_counts_flat_len.restype = u64; L.mirge_counts_flat_len.argtypes = [vp]
     L.mirge_counts_flat_get.argtypes = [vp, vp]
     L.mirge_counts_flat_set.argtypes = [vp, vp]
+    L.mirge_counts_flat_get_dev.argtypes = [vp, vp]
+    L.mirge_counts_flat_set_dev.argtypes = [vp, vp]
     L.mirge_n_unique.restype = u64; L.mirge_n_unique.argtypes = [vp]
     L.mirge_unique.argtypes = [vp, u64, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(C.c_uint8), C.POINTER(C.POINTER(u32))]
     L.mirge_export_uniques.argtypes = [vp, vp, u32, vp, vp, vp, vp]
@@ -282,6 +284,15 @@ class Context:
         buf = np.ascontiguousarray(buf, dtype=np.uint64)
         assert len(buf) == self.L.mirge_counts_flat_len(self.h)
         self._chk(self.L.mirge_counts_flat_set(self.h, buf.ctypes.data))
+
+    def counts_flat_len(self):
+        return int(self.L.mirge_counts_flat_len(self.h))
+
+    def counts_flat_get_dev(self, d_out):
+        self._chk(self.L.mirge_counts_flat_get_dev(self.h, d_out))
+
+    def counts_flat_set_dev(self, d_in):
+        self._chk(self.L.mirge_counts_flat_set_dev(self.h, d_in))
 
     # ---- per-unique results
     def n_unique(self):

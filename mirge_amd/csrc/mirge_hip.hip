@@ -1553,7 +1553,7 @@ int32_t mirge_counts(mirge_ctx* c, const uint64_t** quant, const uint64_t** isca
 uint64_t mirge_counts_flat_len(const mirge_ctx* c) {
     if (!c || !c->libs[MIRGE_LIB_MIRNA].loaded) return 0;
     uint64_t M = c->libs[MIRGE_LIB_MIRNA].names.size(), S = (uint64_t)c->S;
-    return 2 * M * S + 5 * S + (MIRGE_MAX_READ_LEN + 1) * S + S;
+    return 2 * M * S + 5 * S + (MIRGE_MAX_READ_LEN + 1) * S + S + 2 * MIRGE_MAX_ROUNDS;
 }
 int32_t mirge_counts_flat_get(mirge_ctx* c, uint64_t* out) {
     if (!c || !out) return MIRGE_E_ARG;
@@ -1563,7 +1563,8 @@ int32_t mirge_counts_flat_get(mirge_ctx* c, uint64_t* out) {
     memcpy(out + o, c->h_iscan.data(), M * S * 8); o += M * S;
     memcpy(out + o, c->h_cat.data(), 5 * S * 8); o += 5 * S;
     memcpy(out + o, c->h_len.data(), (MIRGE_MAX_READ_LEN + 1) * S * 8); o += (MIRGE_MAX_READ_LEN + 1) * S;
-    memcpy(out + o, c->h_tu.data(), S * 8);
+    memcpy(out + o, c->h_tu.data(), S * 8); o += S;
+    for (int r = 0; r < MIRGE_MAX_ROUNDS; ++r) { out[o + r] = c->stats[r][0]; out[o + MIRGE_MAX_ROUNDS + r] = c->stats[r][1]; }
     return MIRGE_OK;
 }
 int32_t mirge_counts_flat_set(mirge_ctx* c, const uint64_t* in) {
@@ -1574,8 +1575,50 @@ int32_t mirge_counts_flat_set(mirge_ctx* c, const uint64_t* in) {
     memcpy(c->h_iscan.data(), in + o, M * S * 8); o += M * S;
     memcpy(c->h_cat.data(), in + o, 5 * S * 8); o += 5 * S;
     memcpy(c->h_len.data(), in + o, (MIRGE_MAX_READ_LEN + 1) * S * 8); o += (MIRGE_MAX_READ_LEN + 1) * S;
-    memcpy(c->h_tu.data(), in + o, S * 8);
+    memcpy(c->h_tu.data(), in + o, S * 8); o += S;
+    for (int r = 0; r < MIRGE_MAX_ROUNDS; ++r) { c->stats[r][0] = in[o + r]; c->stats[r][1] = in[o + MIRGE_MAX_ROUNDS + r]; }
     return MIRGE_OK;
+}
+
+// the same buffer on the device (for the all-reduce: RCCL reduces device memory, no bounce through the host)
+__global__ void __launch_bounds__(256)
+k_flat_pack(const unsigned long long* __restrict__ arena, uint64_t w_stats, uint64_t qn2, uint64_t w_cat, uint64_t S, int n_rounds,
+            unsigned long long* __restrict__ out) {
+    // arena: [round stats | quant | iscan | categories | 128 x S length histogram | trimmedUniq]; out: the flat layout
+    const uint64_t n_len = (uint64_t)(MIRGE_MAX_READ_LEN + 1) * S, head = qn2 + w_cat;
+    const uint64_t total = head + n_len + S + 2 * MIRGE_MAX_ROUNDS;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        unsigned long long v = 0;
+        if (i < head + n_len) v = arena[w_stats + i];
+        else if (i < head + n_len + S) v = arena[w_stats + head + 128 * S + (i - head - n_len)];
+        else {
+            const uint64_t j = i - head - n_len - S;                 // j < MAX_ROUNDS: processed, else aligned
+            const int r = (int)(j % MIRGE_MAX_ROUNDS), w = (int)(j / MIRGE_MAX_ROUNDS);
+            if (r < n_rounds) for (int sl = 0; sl < STAT_SLOTS; ++sl) v += arena[(size_t)r * STAT_WORDS + ((size_t)w * STAT_SLOTS + sl) * 8];
+        }
+        out[i] = v;
+    }
+}
+int32_t mirge_counts_flat_get_dev(mirge_ctx* c, void* d_out) {
+    if (!c || !d_out) return MIRGE_E_ARG;
+    if (!c->counts_valid || !c->state.p) return fail(c, MIRGE_E_ARG, "count vectors not computed yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t M = c->libs[MIRGE_LIB_MIRNA].names.size(), S = (uint64_t)c->S, qn = std::max<uint64_t>(M * S, 1);
+    if (M * S == 0) return fail(c, MIRGE_E_ARG, "empty miRNA library");
+    hipLaunchKernelGGL(k_flat_pack, dim3(64), dim3(256), 0, c->st, c->state.as<unsigned long long>(), (uint64_t)(MIRGE_MAX_ROUNDS * STAT_WORDS),
+                       2 * qn, 5 * S, S, c->n_rounds, (unsigned long long*)d_out);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return MIRGE_OK;
+}
+int32_t mirge_counts_flat_set_dev(mirge_ctx* c, const void* d_in) {
+    if (!c || !d_in) return MIRGE_E_ARG;
+    if (!c->counts_valid) return fail(c, MIRGE_E_ARG, "count vectors not computed yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> h((size_t)mirge_counts_flat_len(c));
+    HIPCHK(c, hipMemcpyAsync(h.data(), d_in, h.size() * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return mirge_counts_flat_set(c, h.data());
 }
 
 uint64_t mirge_n_unique(const mirge_ctx* c) { return c ? c->cls[0].U + c->cls[1].U : 0; }

@@ -38,6 +38,24 @@ def allreduce_flat(flat: np.ndarray, dist=None, device=None) -> np.ndarray:
     return t.cpu().numpy().view(np.uint64)
 
 
+def allreduce_counts(ctx, dist=None, device=None):
+    """The one collective of a sharded run: sum this context's flat count buffer (count vectors, category totals,
+    length histogram, trimmed_uniq, per-round readsProcessed / readsAligned) over all ranks and install the sums.
+    On GPUs the buffer is packed, reduced (RCCL) and read back from device memory; under gloo (CPU rehearsal) it goes
+    through the host."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    import torch
+    if device is not None and str(device).startswith("cuda") and dist.get_backend() == "nccl":
+        t = torch.empty(ctx.counts_flat_len(), dtype=torch.int64, device=device)
+        ctx.counts_flat_get_dev(t.data_ptr())
+        dist.all_reduce(t)
+        torch.cuda.synchronize(device)
+        ctx.counts_flat_set_dev(t.data_ptr())
+    else:
+        ctx.set_counts_flat(allreduce_flat(ctx.counts_flat(), dist, None))
+
+
 REC16, REC48 = 24, 56          # bytes per record (include/mirge_hip.h: mirge_shard_export)
 
 
@@ -48,22 +66,30 @@ def merge_uniques(ctx, dist, device):
     48-byte classes in one buffer each)."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = device is not None and str(device).startswith("cuda")
+    # gloo (the one-GPU rehearsal of the N > 1 path) has no all-to-all over device buffers: the exchange is then staged
+    # through host tensors; under RCCL the records travel GPU to GPU
+    wire = device if (not on_gpu or dist.get_backend() == "nccl") else None
     n16, n48 = ctx.shard_export_sizes(world)
     send16 = torch.empty(max(int(n16.sum()) * REC16, 8), dtype=torch.uint8, device=device)
     send48 = torch.empty(max(int(n48.sum()) * REC48, 8), dtype=torch.uint8, device=device)
     ctx.shard_export(world, send16.data_ptr(), send48.data_ptr())
-    mine = torch.tensor(np.stack([n16, n48], axis=1).astype(np.int64), device=device)        # [world, 2]: what I send to each rank
+    mine = torch.tensor(np.stack([n16, n48], axis=1).astype(np.int64), device=wire)          # [world, 2]: what I send to each rank
     theirs = torch.empty_like(mine)                                                           # what each rank sends to me
     dist.all_to_all_single(theirs, mine)
     r = theirs.cpu().numpy()
     r16, r48 = r[:, 0], r[:, 1]
-    recv16 = torch.empty(max(int(r16.sum()) * REC16, 8), dtype=torch.uint8, device=device)
-    recv48 = torch.empty(max(int(r48.sum()) * REC48, 8), dtype=torch.uint8, device=device)
+    if wire is not device:
+        send16, send48 = send16.cpu(), send48.cpu()
+    recv16 = torch.empty(max(int(r16.sum()) * REC16, 8), dtype=torch.uint8, device=wire)
+    recv48 = torch.empty(max(int(r48.sum()) * REC48, 8), dtype=torch.uint8, device=wire)
     dist.all_to_all_single(recv16[:int(r16.sum()) * REC16], send16[:int(n16.sum()) * REC16],
                            output_split_sizes=[int(x) * REC16 for x in r16], input_split_sizes=[int(x) * REC16 for x in n16])
     dist.all_to_all_single(recv48[:int(r48.sum()) * REC48], send48[:int(n48.sum()) * REC48],
                            output_split_sizes=[int(x) * REC48 for x in r48], input_split_sizes=[int(x) * REC48 for x in n48])
-    if device is not None and str(device).startswith("cuda"):
+    if wire is not device:
+        recv16, recv48 = recv16.to(device), recv48.to(device)
+    if on_gpu:
         torch.cuda.synchronize(device)
     ctx.shard_import(recv16.data_ptr(), int(r16.sum()), recv48.data_ptr(), int(r48.sum()))
     return int(r16.sum()) + int(r48.sum())

@@ -167,10 +167,26 @@ class Mixture:
     m_subst: float = 0.05
     n_frac: float = 0.002
     hairpin_mm_max: int = 1
+    # Recurring fragments (real small-RNA libraries are dominated by a limited set of tRNA / rRNA fragments and of
+    # unannotated sequences: docs/miRge/miRge.exampleOutput/report.html has 9 % of the other-ncRNA reads and 25 % of the
+    # remaining reads distinct).  pool_* = size of a fixed pool the class draws from (Zipf(1.0) weights; 0 = every
+    # fragment fresh), fresh_* = fraction of the class drawn fresh all the same.
+    pool_other: int = 0
+    fresh_other: float = 1.0
+    pool_random: int = 0
+    fresh_random: float = 1.0
 
     @staticmethod
     def default() -> "Mixture":
         return Mixture()
+
+    @staticmethod
+    def realistic() -> "Mixture":
+        """Class proportions and redundancy of the reference's only published run (report.html:159-175: 1.44M trimmed reads,
+        188,088 distinct; reads 36 % miRNA, 0.07 % hairpin, 39 % other ncRNA, 3.7 % mRNA, 21 % remaining): U/N ~ 0.13 at 20M reads."""
+        return Mixture(mirna=0.36, hairpin=0.001, other=0.39, mrna=0.037, random=0.212,
+                       m_exact=0.85, m_templ=0.10, m_nontempl=0.04, m_subst=0.01,
+                       pool_other=400_000, fresh_other=0.05, pool_random=800_000, fresh_random=0.06)
 
     @staticmethod
     def isomir_rich() -> "Mixture":      # BASELINE.json configs[3]
@@ -213,6 +229,24 @@ def _fragments(rng, lib: Library, n, lo, hi, W):
     return _gather(lib.text, start, lens, W), lens
 
 
+_POOLS = {}
+
+
+def _pooled(rng, key, make_pool, n, fresh_frac, make_fresh, W):
+    """n reads of one class: a fraction fresh_frac made by make_fresh(rng, m), the others drawn with Zipf(1.0) weights
+    from a fixed pool (built once per process by make_pool from a seed of its own, so every chunk and every rank of a
+    run draws from the same pool)."""
+    if key not in _POOLS:
+        ps, pl = make_pool()
+        w = 1.0 / np.arange(1, len(pl) + 1, dtype=np.float64)
+        _POOLS[key] = (ps, pl, np.cumsum(w / w.sum()))
+    ps, pl, cdf = _POOLS[key]
+    nf = int(round(n * fresh_frac))
+    fs, fl = make_fresh(rng, nf)
+    pick = np.minimum(np.searchsorted(cdf, rng.random(n - nf)), len(pl) - 1)
+    return np.concatenate([fs, ps[pick]]), np.concatenate([fl, pl[pick]])
+
+
 def make_reads(libs, n: int, seed: int = BASE_SEED + 1, mixture: Mixture | None = None,
                W: int = 48, zipf_perm_seed: int | None = None):
     """n adapter-trimmed reads: (seqs uint8[n, W] zero padded ASCII, lens uint8[n]).  Lengths 16..47."""
@@ -253,17 +287,30 @@ def make_reads(libs, n: int, seed: int = BASE_SEED + 1, mixture: Mixture | None 
     _substitute(rng, s, ln, rng.integers(0, mx.hairpin_mm_max + 1, size=len(ln)))
     parts_s.append(s); parts_l.append(ln)
     # ---- other ncRNA fragments 16-40 nt, 0-1 substitutions
-    s, ln = _fragments(rng, libs["other"], int(cnt[2]), 16, 40, W)
-    _substitute(rng, s, ln, rng.integers(0, 2, size=len(ln)))
+    def other_frags(r, m):
+        fs, fl = _fragments(r, libs["other"], m, 16, 40, W)
+        _substitute(r, fs, fl, r.integers(0, 2, size=len(fl)))
+        return fs, fl
+    if mx.pool_other:
+        s, ln = _pooled(rng, ("other", id(libs["other"].text), mx.pool_other, W),
+                        lambda: other_frags(np.random.default_rng(BASE_SEED ^ 0x07E2), mx.pool_other), int(cnt[2]), mx.fresh_other, other_frags, W)
+    else:
+        s, ln = other_frags(rng, int(cnt[2]))
     parts_s.append(s); parts_l.append(ln)
     # ---- mRNA fragments 16-45 nt, exact
     s, ln = _fragments(rng, libs["mrna"], int(cnt[3]), 16, 45, W)
     parts_s.append(s); parts_l.append(ln)
     # ---- uniform random 16-45 nt
-    nr = int(cnt[4])
-    ln = rng.integers(16, 46, size=nr)
-    s = ACGT[rng.integers(0, 4, size=(nr, W))]
-    s[np.arange(W)[None, :] >= ln[:, None]] = 0
+    def random_reads(r, m):
+        fl = r.integers(16, 46, size=m)
+        fs = ACGT[r.integers(0, 4, size=(m, W))]
+        fs[np.arange(W)[None, :] >= fl[:, None]] = 0
+        return fs, fl
+    if mx.pool_random:
+        s, ln = _pooled(rng, ("random", mx.pool_random, W), lambda: random_reads(np.random.default_rng(BASE_SEED ^ 0x4A4D), mx.pool_random),
+                        int(cnt[4]), mx.fresh_random, random_reads, W)
+    else:
+        s, ln = random_reads(rng, int(cnt[4]))
     parts_s.append(s); parts_l.append(ln)
     seqs = np.concatenate(parts_s); lens = np.concatenate(parts_l)
     # ---- 0.2 % of reads get one N

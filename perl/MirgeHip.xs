@@ -136,3 +136,27 @@ mirge_counts(ctx, n_samples)
         EXTEND(SP, 5);
         mPUSHs(newRV_noinc((SV*)aq)); mPUSHs(newRV_noinc((SV*)ai)); mPUSHs(newRV_noinc((SV*)ac));
         mPUSHs(newRV_noinc((SV*)al)); mPUSHs(newRV_noinc((SV*)at));
+
+void
+mirge_export_bulk(ctx)
+        MirgeHip ctx
+    PREINIT:
+        uint64_t U, nnz; SV *seqs, *lens, *rnd, *ref, *amb, *uid, *smp, *cnt; const uint32_t stride = 128;
+    PPCODE:
+        /* the whole per-unique result in ONE call, as packed strings for unpack():
+           (U, stride, seqs[U*stride] zero padded, lens "C*", ann_round "c*", ann_ref "l*", ann_amb "C*",
+            nnz, unique id "Q*", sample "L*", count "L*")  -- the sparse unique x sample counts are triplets */
+        U = mirge_n_unique(ctx); nnz = mirge_n_counts(ctx);
+        seqs = newSV(U * stride + 1); lens = newSV(U + 1); rnd = newSV(U + 1); ref = newSV(U * 4 + 1); amb = newSV(U + 1);
+        uid = newSV(nnz * 8 + 1); smp = newSV(nnz * 4 + 1); cnt = newSV(nnz * 4 + 1);
+        SvPOK_only(seqs); SvPOK_only(lens); SvPOK_only(rnd); SvPOK_only(ref); SvPOK_only(amb); SvPOK_only(uid); SvPOK_only(smp); SvPOK_only(cnt);
+        if (mirge_export_uniques(ctx, SvPVX(seqs), stride, (uint8_t*)SvPVX(lens), (int8_t*)SvPVX(rnd), (int32_t*)SvPVX(ref), (uint8_t*)SvPVX(amb)) != MIRGE_OK ||
+            mirge_export_counts(ctx, (uint64_t*)SvPVX(uid), (uint32_t*)SvPVX(smp), (uint32_t*)SvPVX(cnt)) != MIRGE_OK) {
+            SvREFCNT_dec(seqs); SvREFCNT_dec(lens); SvREFCNT_dec(rnd); SvREFCNT_dec(ref); SvREFCNT_dec(amb); SvREFCNT_dec(uid); SvREFCNT_dec(smp); SvREFCNT_dec(cnt);
+            croak("MirgeHip::export_bulk: %s", mirge_last_error(ctx));
+        }
+        SvCUR_set(seqs, U * stride); SvCUR_set(lens, U); SvCUR_set(rnd, U); SvCUR_set(ref, U * 4); SvCUR_set(amb, U);
+        SvCUR_set(uid, nnz * 8); SvCUR_set(smp, nnz * 4); SvCUR_set(cnt, nnz * 4);
+        EXTEND(SP, 11);
+        mPUSHu((UV)U); mPUSHu((UV)stride); mPUSHs(seqs); mPUSHs(lens); mPUSHs(rnd); mPUSHs(ref); mPUSHs(amb);
+        mPUSHu((UV)nnz); mPUSHs(uid); mPUSHs(smp); mPUSHs(cnt);

@@ -176,8 +176,10 @@ def test_partition_invariance(oracle):
                 ctx.collapse_seqs(seqs[r::nshard], 0, lens[r::nshard])
                 ctx.annotate()
                 f = ctx.counts_flat()
-            # trimmedUniq (last S entries) counts uniques per shard, not additive: leave it out
-            tot = f[:-1].copy() if tot is None else tot + f[:-1]
+            # trimmedUniq and the per-round processed / aligned counts (the tail of the buffer) count UNIQUES per shard:
+            # not additive without the unique-table merge, left out here
+            tail = 1 + 2 * capi.MAX_ROUNDS
+            tot = f[:-tail].copy() if tot is None else tot + f[:-tail]
         flats.append(tot)
     assert np.array_equal(flats[0], flats[1]) and np.array_equal(flats[0], flats[2])
 
@@ -361,3 +363,24 @@ def test_random_cascades_vs_oracle(oracle, seed):
         assert np.array_equal(cv[k], res[k]), (k, rounds)
     assert stats == [(int(a), int(b)) for a, b in res["stats"]][:len(rounds)], rounds
     assert sum(b for _, b in stats) > 1000
+
+
+def test_flat_count_buffer_on_the_device(oracle):
+    """mirge_counts_flat_get_dev / _set_dev (the all-reduce buffer left in device memory) against the host forms."""
+    import torch
+    libs, _ = synth.make_libraries(synth.Profile.tiny(), 131)
+    seqs, lens = synth.make_reads(libs, 5000, 132)
+    with capi.Context(None, 2, 0) as ctx:
+        util.load_libs_into(ctx, libs)
+        ctx.collapse_seqs(seqs[:3000], 0, lens[:3000]); ctx.collapse_seqs(seqs[3000:], 1, lens[3000:])
+        ctx.annotate()
+        host = ctx.counts_flat()
+        t = torch.full((ctx.counts_flat_len(),), -1, dtype=torch.int64, device="cuda")
+        ctx.counts_flat_get_dev(t.data_ptr())
+        assert np.array_equal(t.cpu().numpy().view(np.uint64), host)
+        assert host[-2 * capi.MAX_ROUNDS:].sum() > 0                    # the round statistics are in it
+        stats = [ctx.round_stats(r + 1)[:2] for r in range(5)]
+        t *= 3
+        ctx.counts_flat_set_dev(t.data_ptr())
+        assert np.array_equal(ctx.counts_flat(), host * 3)
+        assert [ctx.round_stats(r + 1)[:2] for r in range(5)] == [(3 * a, 3 * b) for a, b in stats]

@@ -108,3 +108,23 @@ def test_batch_cli_writes_the_reference_tables(tmp_path, name):
     bad = subprocess.run([os.path.join(ROOT, "tools", "mirge-annotate"), "--species", str(tmp_path / "nowhere"), "--SampleFiles", case["fastqs"][0]],
                          capture_output=True, text=True)
     assert bad.returncode == 1 and "cannot find" in bad.stderr
+
+
+@pytest.mark.parametrize("name", util.golden_cases())
+def test_perl_full_run_writes_the_reference_tables(tmp_path, name):
+    """perl/t/hotpath.pl --out: the XS call sequence of INTEGRATION.md with ONE bulk export (MirgeHip::export_bulk) instead of
+    an XSUB call per unique, then miRNAmerge / filter / the four tables in Perl: equal to the unmodified reference's tables
+    (the reference ran with orc-bowtie as its bowtie: parity of the matcher's arithmetic itself is unpinned)."""
+    if not shutil.which("perl") or not os.path.exists(os.path.join(ROOT, "perl", "auto", "MirgeHip", "MirgeHip.so")):
+        pytest.skip("perl binding not built")
+    case = util.golden_case(name)
+    out = str(tmp_path / "out")
+    r = subprocess.run(["perl", "-I" + os.path.join(ROOT, "perl"), os.path.join(ROOT, "perl", "t", "hotpath.pl"), "--species", case["species"],
+                        "--out", out, "--names", ",".join(case["names"])] + case["fastqs"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exp = case["expected"]
+    for f in ("miR.Counts.csv", "miR.RPM.csv"):
+        assert open(os.path.join(out, f)).read() == open(os.path.join(exp, f)).read(), f
+    for f in ("mapped.csv", "unmapped.csv"):
+        assert util.rows(os.path.join(out, f)) == util.rows(os.path.join(exp, f)), f
+    assert "[hotpath] export_bulk" in r.stderr
