@@ -27,11 +27,18 @@ extern "C" {
 #define MIRGE_E_ARG        -1   /* bad argument / call order                        */
 #define MIRGE_E_IO         -2   /* file missing or unreadable                       */
 #define MIRGE_E_HIP        -3   /* HIP runtime error (no device, out of memory ...) */
-#define MIRGE_E_FORMAT     -4   /* malformed FASTA/FASTQ, unsupported character     */
+#define MIRGE_E_FORMAT     -4   /* malformed FASTA/FASTQ, control character in a read */
 #define MIRGE_E_LIMIT      -5   /* read longer than MIRGE_MAX_READ_LEN, too many ...*/
 
-#define MIRGE_MAX_READ_LEN 124  /* reads up to 56 nt without N use 16-byte keys;
-                                   longer reads / reads with N use 48-byte keys     */
+/* Reads are whatever line 2 of a FASTQ record holds (miRge.pl:304-306: the hash key is the chomp'ed line).  Reads of
+ * A/C/G/T up to 56 nt travel as 16-byte keys, reads of A/C/G/T/N up to 124 nt as 48-byte keys -- the device-resident
+ * classes.  Everything else up to MIRGE_MAX_READ_LEN -- longer reads, lower case, IUPAC codes, '.' -- is a "verbatim"
+ * read: collapsed by its exact string in a host-side table, matched on the device as bowtie's parser would see it
+ * (a/c/g/t in either case = the base, any other character = N: hypothesis H4 of DESIGN.md section 2, parity unpinned),
+ * and reported like any other unique.  Refused: reads over MIRGE_MAX_READ_LEN (MIRGE_E_LIMIT) and reads holding a
+ * control character, a blank or a byte >= 0x7F, a CR line end among them (MIRGE_E_FORMAT): the reference itself
+ * loses such reads between its hash key and bowtie's read name. */
+#define MIRGE_MAX_READ_LEN 1000
 #define MIRGE_LIB_MIRNA    0    /* miRge.pl:94 */
 #define MIRGE_LIB_HAIRPIN  1    /* miRge.pl:95 */
 #define MIRGE_LIB_OTHER    2    /* miRge.pl:96 */
@@ -109,7 +116,8 @@ int32_t     mirge_collapse_fastq_dev(mirge_ctx*, const void* d_data, uint64_t si
  * 3' adapter removal (error rate 0.12, overlap >= 3) or an unconditional cut, length >= 16 filter, then trim5 / trim3
  * bases off the ends.  adapter as miRge.pl's --adapter: "none", "illumina", "ion", "+N", or up to four comma-separated
  * 3' adapter sequences (A/C/G/T, <= 32 nt).  total_reads / trimmed_reads = logHash totalReads / trimmedReads
- * (miRge.pl:285-288); phred = the value trim_file.py prints (33 or 64).  Raw reads of up to 124 nt.
+ * (miRge.pl:285-288); phred = the value trim_file.py prints (33 or 64).  Raw lines of up to MIRGE_MAX_READ_LEN
+ * characters: a line no key holds (150-nt reads with the adapter still on, lower case ...) is trimmed on its bytes.
  * The quality and adapter algorithms are cutadapt's (third party): parity with it is unpinned, see DESIGN.md. */
 int32_t     mirge_collapse_raw_fastq(mirge_ctx*, const char* raw_fastq, int32_t sample, const char* adapter, int32_t trim5,
                                      int32_t trim3, uint64_t* total_reads, uint64_t* trimmed_reads, int32_t* phred);
@@ -119,8 +127,8 @@ int32_t     mirge_collapse_raw_fastq_mem(mirge_ctx*, const char* data, uint64_t 
 /* Reads from host memory: concatenated ASCII + offs[n+1]. */
 int32_t     mirge_collapse_seqs(mirge_ctx*, const char* seqs, const uint64_t* offs, uint64_t n, int32_t sample);
 /* Reads already resident in HBM as a fixed-width ASCII matrix d_seqs[n][width]
- * (zero padded, width a multiple of 16) + d_lens[n]: 2-bit packing and collapse
- * both run on the device. */
+ * (zero padded, width a multiple of 16) + d_lens[n] (uint8): 2-bit packing and collapse
+ * both run on the device.  The matrix forms take only reads a key can hold (A/C/G/T/N, <= 124 nt). */
 int32_t     mirge_collapse_ascii_dev(mirge_ctx*, const void* d_seqs, uint32_t width, const void* d_lens,
                                      uint64_t n, int32_t sample);
 /* 2-bit packing alone (device to device).  d_keys16 receives the n16 reads that
@@ -185,10 +193,19 @@ int32_t     mirge_counts_flat_set_dev(mirge_ctx*, const void* d_in);
 int32_t     mirge_shard_export_sizes(mirge_ctx*, int32_t world, uint64_t* n16_per_rank, uint64_t* n48_per_rank);
 int32_t     mirge_shard_export(mirge_ctx*, int32_t world, void* d_rec16, void* d_rec48);
 int32_t     mirge_shard_import(mirge_ctx*, const void* d_rec16, uint64_t n16, const void* d_rec48, uint64_t n48);
+/* The same step for the verbatim uniques (host memory, they live in a host table): export = every (sequence, sample,
+ * count) entry of this context as a byte blob [len u32 | sample u32 | count u32 | len bytes]...; the ranks all-gather
+ * their blobs, clear, and import each blob with their own (rank, world): import keeps the entries whose sequence
+ * this rank owns (a hash of the string), counts of equal sequence and sample add. */
+uint64_t    mirge_verb_export_size(const mirge_ctx*);
+int32_t     mirge_verb_export(mirge_ctx*, void* blob);
+int32_t     mirge_verb_clear(mirge_ctx*);
+int32_t     mirge_verb_import(mirge_ctx*, const void* blob, uint64_t nbytes, int32_t rank, int32_t world);
 
 /* ---- per-unique results (feeds mapped.csv / unmapped.csv, miRge.pl:702-752,
  *      845-863) -------------------------------------------------------------- */
-uint64_t    mirge_n_unique(const mirge_ctx*);
+uint64_t    mirge_n_unique(const mirge_ctx*);                 /* numbered [16-byte keys | 48-byte keys | verbatim] */
+uint32_t    mirge_max_unique_len(const mirge_ctx*);           /* an upper bound: the stride mirge_export_uniques needs */
 /* ref_idx[r] = reference index in round r+1's library, or -1 (at most one round
  * is set: a unique annotated in round r is never offered to later rounds,
  * miRge.pl:382, 445).  ambiguous: bit r set iff round r+1's best stratum held
@@ -196,7 +213,7 @@ uint64_t    mirge_n_unique(const mirge_ctx*);
 int32_t     mirge_unique(mirge_ctx*, uint64_t i, const char** seq, int32_t ref_idx[MIRGE_MAX_ROUNDS],
                          uint8_t* ambiguous, const uint32_t** counts);
 /* Bulk form: seqs[U][stride] zero padded; any pointer may be NULL. */
-int32_t     mirge_export_uniques(mirge_ctx*, char* seqs, uint32_t stride, uint8_t* lens, int8_t* ann_round,
+int32_t     mirge_export_uniques(mirge_ctx*, char* seqs, uint32_t stride, uint16_t* lens, int8_t* ann_round,
                                  int32_t* ann_ref, uint8_t* ann_amb);
 /* Sparse unique x sample counts as triplets. */
 uint64_t    mirge_n_counts(const mirge_ctx*);

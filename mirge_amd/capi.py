@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("MIRGE_HIP_LIB") or os.path.join(HERE, "libmirge_hip.s
 
 LIB_MIRNA, LIB_HAIRPIN, LIB_OTHER, LIB_MRNA = 0, 1, 2, 3
 MAX_ROUNDS = 8
-MAX_READ_LEN = 124
+MAX_READ_LEN = 1000      # MIRGE_MAX_READ_LEN
+MAX_KEY_LEN = 124        # longest read a device-resident key holds
 NOALLOC_MAX_KEYS = 1 << 20
 
 EXPORTS = [
@@ -25,7 +26,8 @@ EXPORTS = [
     "mirge_shard_export_sizes", "mirge_shard_export", "mirge_shard_import",
     "mirge_collapse_fastq", "mirge_collapse_fastq_mem", "mirge_collapse_fastq_dev", "mirge_collapse_seqs", "mirge_collapse_ascii_dev", "mirge_pack_dev",
     "mirge_collapse_packed_dev", "mirge_annotate", "mirge_round_stats", "mirge_counts", "mirge_counts_flat_len",
-    "mirge_counts_flat_get", "mirge_counts_flat_set", "mirge_counts_flat_get_dev", "mirge_counts_flat_set_dev", "mirge_n_unique", "mirge_unique", "mirge_export_uniques",
+    "mirge_counts_flat_get", "mirge_counts_flat_set", "mirge_counts_flat_get_dev", "mirge_counts_flat_set_dev", "mirge_n_unique", "mirge_max_unique_len", "mirge_unique", "mirge_export_uniques",
+    "mirge_verb_export_size", "mirge_verb_export", "mirge_verb_clear", "mirge_verb_import",
     "mirge_n_counts", "mirge_export_counts", "mirge_last_timing", "mirge_kernel_times", "mirge_write_tables",
     "mirge_collapse_keys16_noalloc",
 ]
@@ -97,6 +99,11 @@ def load():
     L.mirge_counts_flat_get_dev.argtypes = [vp, vp]
     L.mirge_counts_flat_set_dev.argtypes = [vp, vp]
     L.mirge_n_unique.restype = u64; L.mirge_n_unique.argtypes = [vp]
+    L.mirge_max_unique_len.restype = u32; L.mirge_max_unique_len.argtypes = [vp]
+    L.mirge_verb_export_size.restype = u64; L.mirge_verb_export_size.argtypes = [vp]
+    L.mirge_verb_export.argtypes = [vp, vp]
+    L.mirge_verb_clear.argtypes = [vp]
+    L.mirge_verb_import.argtypes = [vp, vp, u64, i32, i32]
     L.mirge_unique.argtypes = [vp, u64, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(C.c_uint8), C.POINTER(C.POINTER(u32))]
     L.mirge_export_uniques.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     L.mirge_n_counts.restype = u64; L.mirge_n_counts.argtypes = [vp]
@@ -299,18 +306,32 @@ class Context:
         return self.L.mirge_n_unique(self.h)
 
     def export_uniques(self, with_seqs=True):
-        """(seqs[U][128] zero padded, lens, ann_round, ann_ref, ann_amb); with_seqs=False leaves the sequences out
+        """(seqs[U][stride] zero padded, lens, ann_round, ann_ref, ann_amb); with_seqs=False leaves the sequences out
         (seqs and lens come back as None): the annotation arrays of a 50M-unique table without 7 GB of text."""
         U = self.n_unique()
-        stride = 128
+        stride = max(128, (int(self.L.mirge_max_unique_len(self.h)) + 15) // 16 * 16)
         seqs = np.zeros((max(U, 1), stride), dtype=np.uint8) if with_seqs else None
-        lens = np.zeros(max(U, 1), dtype=np.uint8) if with_seqs else None
+        lens = np.zeros(max(U, 1), dtype=np.uint16) if with_seqs else None
         rnd = np.zeros(max(U, 1), dtype=np.int8); ref = np.zeros(max(U, 1), dtype=np.int32); amb = np.zeros(max(U, 1), dtype=np.uint8)
         self._chk(self.L.mirge_export_uniques(self.h, seqs.ctypes.data if with_seqs else None, stride,
                                               lens.ctypes.data if with_seqs else None, rnd.ctypes.data, ref.ctypes.data, amb.ctypes.data))
         if not with_seqs:
             return None, None, rnd[:U], ref[:U], amb[:U]
         return seqs[:U], lens[:U], rnd[:U], ref[:U], amb[:U]
+
+    # ---- verbatim uniques across ranks (host blobs)
+    def verb_export(self):
+        n = int(self.L.mirge_verb_export_size(self.h))
+        buf = np.zeros(max(n, 1), dtype=np.uint8)
+        self._chk(self.L.mirge_verb_export(self.h, buf.ctypes.data))
+        return buf[:n]
+
+    def verb_clear(self):
+        self._chk(self.L.mirge_verb_clear(self.h))
+
+    def verb_import(self, blob, rank, world):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._chk(self.L.mirge_verb_import(self.h, blob.ctypes.data if len(blob) else None, len(blob), rank, world))
 
     def export_counts(self):
         n = self.L.mirge_n_counts(self.h)

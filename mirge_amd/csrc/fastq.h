@@ -112,6 +112,25 @@ MG_HD int fq_pack_read(const uint8_t* __restrict__ data, uint64_t size, uint64_t
     return bad ? 4 : 0;
 }
 
+// A sequence line that does not fit a key (longer than 124 nt, or holding characters other than A C G T N): its
+// length and whether the library takes it at all.  0 = yes (a "verbatim" read: collapsed by exact string on the host,
+// matched as N where it is not a/c/g/t), 4 = holds a control character, a blank or a byte >= 0x7F (a "\r" among them on
+// the trimmed path, where chomp leaves it in the key, miRge.pl:304), 5 = longer than FQ_MAX_LINE.
+constexpr int FQ_MAX_LINE = 1000;         // = MIRGE_MAX_READ_LEN (include/mirge_hip.h)
+template <bool CR>
+MG_HD int fq_line_scan(const uint8_t* __restrict__ data, uint64_t size, uint64_t s, int& len) {
+    len = 0;
+    for (uint64_t p = s; p < size; ++p) {
+        const uint8_t ch = data[p];
+        if (ch == '\n' || (CR && ch == '\r')) break;
+        if (ch <= 0x20 || ch >= 0x7F) return 4;
+        if (++len > FQ_MAX_LINE) return 5;
+    }
+    return 0;
+}
+// verbatim-read list entry: record index | first byte of the read inside the sequence line << 32 | its length << 48
+MG_HD uint64_t fq_odd_entry(uint64_t i, int a, int len) { return i | ((uint64_t)a << 32) | ((uint64_t)len << 48); }
+
 #ifdef __HIPCC__
 __global__ void __launch_bounds__(256)
 k_fq_count(const uint8_t* __restrict__ data, uint64_t size, uint32_t* __restrict__ seg_nl) {
@@ -145,17 +164,20 @@ k_fq_index(const uint8_t* __restrict__ data, uint64_t size, uint64_t file_off, u
     if (c) fq_index64(w, off, size, file_off, o0 + seg_base[blockIdx.x] + buf[threadIdx.x] - c, start, qstart, qend);
 }
 
-// counters as in k_pack: [0] n16, [1] n48, [2] error code, [3] first offending record
+// counters as in k_pack: [0] n16, [1] n48, [2] error code, [3] first offending record; [7] verbatim reads, [8] their bytes
 __global__ void __launch_bounds__(256)
 k_fq_pack(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* __restrict__ start, uint64_t n,
-          uint64_t* __restrict__ k16, uint64_t* __restrict__ k48, unsigned long long* counters) {
+          uint64_t* __restrict__ k16, uint64_t* __restrict__ k48, uint64_t* __restrict__ odd, unsigned long long* counters) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t s = start[i];
     uint64_t sq[4], nm[2]; int len; bool hasN;
     int rc = fq_pack_read(data, size, s == FQ_NONE ? size : s, sq, nm, len, hasN);
-    if (rc) {
-        if (atomicCAS(&counters[2], 0ull, (unsigned long long)rc) == 0ull) counters[3] = i;
+    if (rc) {                                                  // no key holds it: a verbatim read, or an input error
+        rc = fq_line_scan<false>(data, size, s, len);
+        if (rc) { if (atomicCAS(&counters[2], 0ull, (unsigned long long)rc) == 0ull) counters[3] = i; return; }
+        odd[atomicAdd(&counters[7], 1ull)] = fq_odd_entry(i, 0, len);
+        atomicAdd(&counters[8], (unsigned long long)len);
         return;
     }
     if (!hasN && len <= 56) {
@@ -168,6 +190,20 @@ k_fq_pack(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* __res
         k48[6 * p + 3] = sq[3] | ((uint64_t)len << 56);
         k48[6 * p + 4] = nm[0]; k48[6 * p + 5] = nm[1];
     }
+}
+
+// verbatim reads -> one byte pool for the host: tab[j] = offset in the pool << 16 | length
+__global__ void __launch_bounds__(256)
+k_fq_odd_gather(const uint8_t* __restrict__ data, const uint64_t* __restrict__ start, const uint64_t* __restrict__ odd, uint64_t m,
+                uint8_t* __restrict__ pool, uint64_t* __restrict__ tab, unsigned long long* cursor) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t e = odd[j];
+    const uint64_t s = start[e & 0xFFFFFFFFull] + ((e >> 32) & 0xFFFF);
+    const uint32_t len = (uint32_t)(e >> 48);
+    const uint64_t off = atomicAdd(cursor, (unsigned long long)len);
+    tab[j] = (off << 16) | len;
+    for (uint32_t q = 0; q < len; ++q) pool[off + q] = data[s + q];
 }
 #endif
 

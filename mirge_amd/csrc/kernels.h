@@ -1264,6 +1264,99 @@ __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, 
     return true;
 }
 
+// ==========================================================================================
+// Verbatim uniques: reads no key can hold -- longer than 124 nt, or holding characters other than A C G T N, which
+// miRge.pl:306 keeps apart by their exact string (the collapse of these is a host-side string table, mirge_hip.hip).
+// They are matched in the matcher's alphabet (a/c/g/t in either case = the base, every other character = N:
+// hypothesis H4) with the same policy as every other read, serially, one thread per unique:
+// candidates from the one-strand k-mer index by the pigeonhole pieces, each verified on the text word by word.
+// Record of a unique in the pool: [ sq fwd (WS) | N mask fwd (WN) | sq reverse complement (WS) | N mask rc (WN) ],
+// WS = ceil(len / 32) + 1, WN = ceil(len / 64) + 1 words (one word of zeros behind each part: every access below
+// loads two neighbouring words).
+MG_HD int verb_ws(int len) { return (len + 31) / 32 + 1; }
+MG_HD int verb_wn(int len) { return (len + 63) / 64 + 1; }
+MG_HD int verb_words(int len) { return 2 * (verb_ws(len) + verb_wn(len)); }
+// host: the record of one read out of its characters
+inline void verb_pack(const char* s, int len, uint64_t* rec) {
+    const int WS = verb_ws(len), WN = verb_wn(len);
+    for (int i = 0; i < verb_words(len); ++i) rec[i] = 0;
+    uint64_t *sf = rec, *nf = rec + WS, *sr = rec + WS + WN, *nr = rec + 2 * WS + WN;
+    for (int i = 0; i < len; ++i) {
+        uint8_t ch = (uint8_t)s[i];
+        if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32);
+        const int code = base_code(ch), j = len - 1 - i;
+        if (code >= 0 && code < 4) { sf[i >> 5] |= (uint64_t)code << (2 * (i & 31)); sr[j >> 5] |= (uint64_t)(3 - code) << (2 * (j & 31)); }
+        else { nf[i >> 6] |= 1ull << (i & 63); nr[j >> 6] |= 1ull << (j & 63); }
+    }
+}
+MG_HD uint64_t lw_bits(const uint64_t* __restrict__ x, int bp) {
+    const int wi = bp >> 6, bs = bp & 63;
+    const uint64_t lo = x[wi], hi = x[wi + 1];
+    return bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+}
+struct LongRead { const uint64_t* sq[2]; const uint64_t* nm[2]; int ob[2]; int l, s, span; bool ok; };     // [1] forward, [0] reverse complement
+MG_HD void long_setup(const uint64_t* __restrict__ rec, int len, const RoundDev& P, LongRead& R) {
+    const int WS = verb_ws(len), WN = verb_wn(len);
+    R.sq[1] = rec; R.nm[1] = rec + WS; R.sq[0] = rec + WS + WN; R.nm[0] = rec + 2 * WS + WN;
+    R.ob[1] = P.trim5; R.ob[0] = P.trim3;                      // bowtie -5 / -3: the trimmed read starts trim3 nt into the reverse complement
+    R.l = len - P.trim5 - P.trim3;
+    R.ok = !(R.l <= 0 || R.l <= P.seedmm);
+    R.s = P.seedlen < R.l ? P.seedlen : R.l;
+    R.span = round_whole(P) ? R.l : R.s;
+}
+MG_HD bool long_window_ok(const LibDev& L, const LongRead& R, int fw, int64_t w, const RoundDev& P, int& sm_out, int& tm_out) {
+    const int l = R.l;
+    if (w < 0 || w + l > (int64_t)L.T) return false;
+    const int sa = fw ? 0 : l - R.s, sb = fw ? R.s : l;        // the seed = the read's first s nt, wherever the strand puts them
+    int tm = 0, sm = 0;
+    for (int j = 0; 32 * j < l; ++j) {
+        const uint64_t r = lw_bits(R.sq[fw], 2 * (R.ob[fw] + 32 * j));
+        const uint64_t n = spread32((uint32_t)lw_bits(R.nm[fw], R.ob[fw] + 32 * j));
+        const uint64_t x = text_bits64(L.text, w + 32 * j);
+        uint64_t d = x ^ r;
+        d = (((d | (d >> 1)) & M55) | n) & ones(2 * (l - 32 * j));             // a read N mismatches everything
+        const uint64_t sd = (ones(2 * (sb - 32 * j)) ^ ones(2 * (sa - 32 * j))) & M55;
+        tm += popc64(d); sm += popc64(d & sd);
+        if (tm > P.maxmm) return false;
+    }
+    if (sm > P.seedmm) return false;
+    for (int j = 0; 64 * j < l; ++j) if (bad_bits64(L.bad, w + 64 * j) & ones(l - 64 * j)) return false;      // reference N / boundary
+    sm_out = sm; tm_out = tm;
+    return true;
+}
+__host__ __device__ inline void match_long(const uint64_t* __restrict__ rec, int len, const LibDev& L, const RoundDev& P,
+                                           uint64_t& score, uint64_t& kmax, uint64_t& kmin) {
+    score = 0; kmax = 0; kmin = 0;
+    LongRead R;
+    long_setup(rec, len, P, R);
+    if (!R.ok) return;
+    const int np = round_np(P);
+    for (int p = 0; p < np; ++p) {
+        if (!piece_needed(P, p, score)) break;
+        const int ps = piece_cut(R.span, p, np), pe = piece_cut(R.span, p + 1, np);
+        for (int fw = 1; fw >= 0; --fw) {
+            const int qs = fw ? ps : R.l - pe;
+            const int kq = pe - ps < L.kb ? pe - ps : L.kb;
+            if (kq <= 0) continue;
+            if (lw_bits(R.nm[fw], R.ob[fw] + qs) & ones(kq)) continue;         // a piece holding a read N is not the exact one
+            const uint64_t v = lw_bits(R.sq[fw], 2 * (R.ob[fw] + qs)) & ones(2 * kq);
+            const uint32_t code = (uint32_t)(rev2(v) >> (64 - 2 * kq));
+            const int sh = 2 * (L.kb - kq);
+            uint32_t lo, hi;
+            koff_range(L, (uint64_t)code << sh, ((uint64_t)code + 1) << sh, lo, hi);
+            for (uint32_t c = lo; c < hi; ++c) {
+                const uint32_t pos = L.kent[c].pos;
+                if (pos < (uint32_t)qs) continue;
+                const uint32_t w = pos - (uint32_t)qs;
+                int sm, tm;
+                if (!long_window_ok(L, R, fw, (int64_t)w, P, sm, tm)) continue;
+                const uint64_t x = hit_score(sm, tm, w, fw), y = hit_kmax(sm, w), z = hit_kmin(sm, w);
+                score = x > score ? x : score; kmax = y > kmax ? y : kmax; kmin = z > kmin ? z : kmin;
+            }
+        }
+    }
+}
+
 // One cascade round over the unique table: eligibility (miRge.pl:382-393), match, mark
 // (miRge.pl:445-446).  stats: [0] processed, [1] aligned (miRge.pl:409-413).
 //
@@ -1776,6 +1869,65 @@ k_counts(const uint32_t* __restrict__ coo_g, const uint32_t* __restrict__ coo_c,
         if (s_q[j]) atomicAdd(&quant[(uint64_t)j * S + sample], s_q[j]);
         if (s_i[j]) atomicAdd(&iscan[(uint64_t)j * S + sample], s_i[j]);
     }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// One cascade round over the verbatim uniques (match_long), and their share of the count vectors.  A rare class:
+// thread per unique, global atomics.
+__global__ void __launch_bounds__(256)
+k_match_verb(const uint64_t* __restrict__ pool, const uint64_t* __restrict__ off, const uint32_t* __restrict__ len, uint32_t U,
+             uint8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb, LibDev L, RoundDev P, int r, unsigned long long* stats) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = false, hit = false;
+    if (u < U) {
+        uint8_t before = 0;
+        if (r == 0) { ann_round[u] = 0; ann_ref[u] = -1; ann_amb[u] = 0; }
+        else before = ann_round[u];
+        const int l = (int)len[u];
+        active = before == 0 && !(P.len_lt && !(l < P.len_lt)) && !(P.len_gt && !(l > P.len_gt));      // miRge.pl:382-393
+        if (active) {
+            uint64_t score, kmax, kmin;
+            match_long(pool + off[u], l, L, P, score, kmax, kmin);
+            if (score) {
+                hit = true;
+                const uint32_t ref = ref_of(L, (uint32_t)(score >> 1));
+                ann_round[u] = (uint8_t)(r + 1); ann_ref[u] = (int32_t)ref;
+                ann_amb[u] = (uint8_t)(ref_of(L, (uint32_t)kmax) != ref_of(L, 0xFFFFFFFFu - (uint32_t)kmin));
+            }
+        }
+    }
+    const unsigned long long am = __ballot(active), hm = __ballot(hit);
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) & (STAT_SLOTS - 1);
+        if (am) atomicAdd(&stats[(size_t)slot * 8], (unsigned long long)__popcll(am));
+        if (hm) atomicAdd(&stats[(size_t)(STAT_SLOTS + slot) * 8], (unsigned long long)__popcll(hm));
+    }
+}
+// entries (unique, sample, count), at most one per pair
+__global__ void __launch_bounds__(256)
+k_counts_verb(const uint32_t* __restrict__ coo_u, const uint32_t* __restrict__ coo_s, const uint32_t* __restrict__ coo_c, uint32_t n, int S,
+              const uint32_t* __restrict__ len, const uint8_t* __restrict__ ann_round, const int32_t* __restrict__ ann_ref,
+              uint32_t round_libs, uint32_t iscan_rounds, int len_bins, unsigned long long* quant, unsigned long long* iscan,
+              unsigned long long* cat, unsigned long long* lenhist, unsigned long long* tuniq) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t g = coo_u[e], s = coo_s[e];
+    const unsigned long long c = coo_c[e];
+    const int r = ann_round[g];
+    atomicAdd(&tuniq[s], 1ull);                                                  // miRge.pl:468
+    if ((int)len[g] < len_bins) atomicAdd(&lenhist[(uint64_t)len[g] * S + s], c);  // miRge.pl:315
+    int catidx = 4;
+    if (r > 0) {
+        const int lib = (int)((round_libs >> (2 * (r - 1))) & 3u);
+        catidx = lib;
+        if (lib == 0) {
+            const int32_t m = ann_ref[g];
+            atomicAdd(&quant[(uint64_t)m * S + s], c);
+            if ((iscan_rounds >> (r - 1)) & 1u) atomicAdd(&iscan[(uint64_t)m * S + s], c);
+        }
+    }
+    atomicAdd(&cat[(uint64_t)catidx * S + s], c);
 }
 
 }  // namespace mg

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -113,6 +114,7 @@ struct Lib {
 };
 
 constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
+constexpr int LEN_BINS = MIRGE_MAX_READ_LEN + 1;          // read-length histogram rows (miRge.pl:315)
 
 struct Segment { int sample; uint64_t start, count; };
 
@@ -142,6 +144,28 @@ struct Class {
                      pt_k1.release(); pt_w1.release(); pt_k2.release(); pt_w2.release(); pt_cur.release(); }
 };
 
+// Verbatim uniques (kernels.h: match_long): reads no key can hold, collapsed by their exact string as miRge.pl:306 does.
+// A host-side table -- in small-RNA data they are the odd read; a run made of nothing else (150-nt reads, --adapter none)
+// works, at the pace of a host hash map.
+struct Verb {
+    std::unordered_map<std::string, uint32_t> index;
+    std::vector<std::string> seq;
+    std::unordered_map<uint64_t, uint32_t> entry;              // unique * S + sample -> position in the entry arrays
+    std::vector<uint32_t> coo_u, coo_s, coo_c;
+    uint32_t maxlen = 0;
+    DevBuf pool, off, len, ann_round, ann_ref, ann_amb, d_u, d_s, d_c;
+    void reset() { index.clear(); seq.clear(); entry.clear(); coo_u.clear(); coo_s.clear(); coo_c.clear(); maxlen = 0; }
+    void release() { pool.release(); off.release(); len.release(); ann_round.release(); ann_ref.release(); ann_amb.release(); d_u.release(); d_s.release(); d_c.release(); }
+    void add(const char* s, size_t n, int sample, int S, uint32_t count) {
+        auto it = index.emplace(std::string(s, n), (uint32_t)seq.size());
+        if (it.second) { seq.push_back(it.first->first); if (n > maxlen) maxlen = (uint32_t)n; }
+        const uint32_t u = it.first->second;
+        auto e = entry.emplace((uint64_t)u * (uint64_t)S + (uint64_t)sample, (uint32_t)coo_u.size());
+        if (e.second) { coo_u.push_back(u); coo_s.push_back((uint32_t)sample); coo_c.push_back(count); }
+        else coo_c[e.first->second] += count;
+    }
+};
+
 struct KTime { const char* name; hipEvent_t a = nullptr, b = nullptr; bool used = false; double ms = 0; uint64_t bytes = 0; };
 
 }  // namespace
@@ -160,6 +184,8 @@ struct mirge_ctx {
                                                     // overflow the LDS queue, so more of them stay with their thread (MIRGE_COOP_THR3)
     mirge_round rounds[MIRGE_MAX_ROUNDS];
     Class cls[2];                                   // [0] 16-byte keys, [1] 48-byte keys
+    Verb vb;                                        // the reads neither holds
+    DevBuf fq_odd, fq_oddtab, fq_oddpool;           // FASTQ ingest: verbatim-read list, their bytes for the host
     // workspaces
     DevBuf ctr, stage16, stage48, in_seqs, in_lens, scan_tmp, hist, off_tmp;
     DevBuf sh_ctr, sh_w[2];                         // multi-GPU exchange: per-owner / per-sample counters, weights of imported records
@@ -179,8 +205,8 @@ struct mirge_ctx {
     std::vector<uint64_t> h_quant, h_iscan, h_cat, h_len, h_tu;
     // host copies for per-unique export
     std::vector<uint64_t> h_keys[2];
-    std::vector<uint8_t> h_round[2], h_amb[2];
-    std::vector<int32_t> h_ref[2];
+    std::vector<uint8_t> h_round[3], h_amb[3];      // [2]: the verbatim uniques
+    std::vector<int32_t> h_ref[3];
     std::vector<uint32_t> h_coo_g[2], h_coo_c[2];
     std::vector<uint64_t> csr_off; std::vector<uint32_t> csr_sample, csr_count;
     std::string uniq_seq; std::vector<uint32_t> uniq_counts;
@@ -628,42 +654,93 @@ int pack_launch(mirge_ctx* c, const void* d_seqs, uint32_t width, const void* d_
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 32, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
-    if (c->h_ctr[2] == 4) return fail(c, MIRGE_E_FORMAT, "read " + std::to_string(c->h_ctr[3]) + " holds a character other than A, C, G, T, N");
-    if (c->h_ctr[2] == 5) return fail(c, MIRGE_E_LIMIT, "read " + std::to_string(c->h_ctr[3]) + " is longer than " + std::to_string(MIRGE_MAX_READ_LEN) + " nt");
+    if (c->h_ctr[2] == 4) return fail(c, MIRGE_E_FORMAT, "row " + std::to_string(c->h_ctr[3]) + " of the ASCII matrix holds a character other than A, C, G, T, N (the matrix form takes reads a key can hold)");
+    if (c->h_ctr[2] == 5) return fail(c, MIRGE_E_LIMIT, "row " + std::to_string(c->h_ctr[3]) + " of the ASCII matrix is longer than " + std::to_string(KeyTraits<6>::MAXLEN) + " nt (the matrix form takes reads a key can hold)");
     return MIRGE_OK;
 }
 
-// host reads (concatenated + offsets) -> chunks of ASCII matrix -> device pack -> collapse
+// 0 = a key holds the read, 1 = a verbatim read, 4 / 5 = refused (control character or blank / longer than MIRGE_MAX_READ_LEN)
+inline int read_kind(const char* s, uint64_t l) {
+    if (l > MIRGE_MAX_READ_LEN) return 5;
+    bool plain = l <= (uint64_t)KeyTraits<6>::MAXLEN;
+    for (uint64_t i = 0; i < l; ++i) {
+        const uint8_t ch = (uint8_t)s[i];
+        if (ch <= 0x20 || ch >= 0x7F) return 4;
+        plain = plain && base_code(ch) >= 0;
+    }
+    return plain ? 0 : 1;
+}
+int host_threads() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("MIRGE_HOST_THREADS")) n = atoi(e);
+    return std::max(1, std::min(n, 16));
+}
+// fn(lo, hi, t) over [0, n) cut into one slice per thread
+template <class F> void parallel_slices(uint64_t n, int nthr, F fn) {
+    if (nthr <= 1 || n < 4096) { fn((uint64_t)0, n, 0); return; }
+    std::vector<std::thread> thr;
+    for (int t = 0; t < nthr; ++t) thr.emplace_back([&, t] { fn(n * t / nthr, n * (t + 1) / nthr, t); });
+    for (auto& x : thr) x.join();
+}
+int verb_refused(mirge_ctx* c, int kind, uint64_t read) {
+    if (kind == 4) return fail(c, MIRGE_E_FORMAT, "read " + std::to_string(read) + " holds a control character, a blank or a byte outside ASCII (a CR line end among them)");
+    return fail(c, MIRGE_E_LIMIT, "read " + std::to_string(read) + " is longer than " + std::to_string(MIRGE_MAX_READ_LEN) + " nt");
+}
+
+// host reads (concatenated + offsets) -> chunks of ASCII matrix -> device pack -> collapse.  The staging (classify every
+// read, lay the ones a key holds out as matrix rows) runs on the host's threads; reads no key holds go to the verbatim table.
 int collapse_host(mirge_ctx* c, const char* seqs, const uint64_t* offs, uint64_t n, int sample) {
     if (sample < 0 || sample >= c->S) return fail(c, MIRGE_E_ARG, "sample index out of range");
-    uint64_t maxlen = 0;
-    for (uint64_t i = 0; i < n; ++i) maxlen = std::max(maxlen, offs[i + 1] - offs[i]);
-    if (maxlen > MIRGE_MAX_READ_LEN) return fail(c, MIRGE_E_LIMIT, "a read is longer than " + std::to_string(MIRGE_MAX_READ_LEN) + " nt");
-    uint32_t W = (uint32_t)std::max<uint64_t>(16, (maxlen + 15) / 16 * 16);
+    const int nthr = host_threads();
     const uint64_t CH = 1u << 22;
-    HIPCHK(c, c->ctr.ensure(64, false, 0, c->st));
-    HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 64, c->st));
+    HIPCHK(c, c->ctr.ensure(128, false, 0, c->st));
+    HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 128, c->st));
     HIPCHK(c, c->stage16.ensure(std::max<uint64_t>(n, 1) * 16, false, 0, c->st));
-    std::vector<uint8_t> mat, lens;
-    uint64_t n48 = 0;
+    std::vector<uint8_t> mat, lens, kind;
+    uint64_t n16 = 0, n48 = 0;
     for (uint64_t b = 0; b < n; b += CH) {
-        uint64_t m = std::min(CH, n - b);
-        mat.assign((size_t)m * W, 0); lens.resize((size_t)m);
-        for (uint64_t i = 0; i < m; ++i) {
-            uint64_t l = offs[b + i + 1] - offs[b + i];
-            memcpy(&mat[(size_t)i * W], seqs + offs[b + i], (size_t)l);
-            lens[(size_t)i] = (uint8_t)l;
+        const uint64_t m = std::min(CH, n - b);
+        kind.resize((size_t)m);
+        std::vector<uint64_t> t_plain((size_t)nthr + 1, 0), t_max((size_t)nthr, 0);
+        parallel_slices(m, nthr, [&](uint64_t lo, uint64_t hi, int t) {
+            uint64_t np = 0, mx = 0;
+            for (uint64_t i = lo; i < hi; ++i) {
+                const uint64_t l = offs[b + i + 1] - offs[b + i];
+                const int k = read_kind(seqs + offs[b + i], l);
+                kind[(size_t)i] = (uint8_t)k;
+                if (k == 0) { ++np; mx = std::max(mx, l); }
+            }
+            t_plain[(size_t)t + 1] = np; t_max[(size_t)t] = mx;
+        });
+        for (uint64_t i = 0; i < m; ++i) if (kind[(size_t)i] > 1) return verb_refused(c, kind[(size_t)i], b + i);
+        uint64_t maxlen = 0;
+        for (int t = 0; t < nthr; ++t) { t_plain[(size_t)t + 1] += t_plain[(size_t)t]; maxlen = std::max(maxlen, t_max[(size_t)t]); }
+        const uint64_t rows = t_plain[(size_t)nthr];
+        const uint32_t W = (uint32_t)std::max<uint64_t>(16, (maxlen + 15) / 16 * 16);
+        if (rows) {
+            mat.assign((size_t)rows * W, 0); lens.resize((size_t)rows);
+            parallel_slices(m, nthr, [&](uint64_t lo, uint64_t hi, int t) {
+                uint64_t r = m < 4096 || nthr <= 1 ? 0 : t_plain[(size_t)t];
+                for (uint64_t i = lo; i < hi; ++i) {
+                    if (kind[(size_t)i]) continue;
+                    const uint64_t l = offs[b + i + 1] - offs[b + i];
+                    memcpy(&mat[(size_t)r * W], seqs + offs[b + i], (size_t)l);
+                    lens[(size_t)r] = (uint8_t)l; ++r;
+                }
+            });
+            HIPCHK(c, c->in_seqs.ensure((size_t)rows * W, false, 0, c->st));
+            HIPCHK(c, c->in_lens.ensure((size_t)rows, false, 0, c->st));
+            HIPCHK(c, c->stage48.ensure((n48 + rows) * 48, true, n48 * 48, c->st));
+            HIPCHK(c, hipMemcpyAsync(c->in_seqs.p, mat.data(), (size_t)rows * W, hipMemcpyHostToDevice, c->st));
+            HIPCHK(c, hipMemcpyAsync(c->in_lens.p, lens.data(), (size_t)rows, hipMemcpyHostToDevice, c->st));
+            int rc = pack_launch(c, c->in_seqs.p, W, c->in_lens.p, rows, c->stage16.p, c->stage48.p);
+            if (rc) return rc;
+            n16 = c->h_ctr[0]; n48 = c->h_ctr[1];
         }
-        HIPCHK(c, c->in_seqs.ensure((size_t)m * W, false, 0, c->st));
-        HIPCHK(c, c->in_lens.ensure((size_t)m, false, 0, c->st));
-        HIPCHK(c, c->stage48.ensure((n48 + m) * 48, true, n48 * 48, c->st));
-        HIPCHK(c, hipMemcpyAsync(c->in_seqs.p, mat.data(), (size_t)m * W, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipMemcpyAsync(c->in_lens.p, lens.data(), (size_t)m, hipMemcpyHostToDevice, c->st));
-        int rc = pack_launch(c, c->in_seqs.p, W, c->in_lens.p, m, c->stage16.p, c->stage48.p);
-        if (rc) return rc;
-        n48 = c->h_ctr[1];
+        if (rows < m)
+            for (uint64_t i = 0; i < m; ++i)
+                if (kind[(size_t)i] == 1) c->vb.add(seqs + offs[b + i], (size_t)(offs[b + i + 1] - offs[b + i]), sample, c->S, 1);
     }
-    uint64_t n16 = n ? c->h_ctr[0] : 0;
     return collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
 }
 
@@ -697,7 +774,7 @@ int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t la
     if ((uintptr_t)d & 15) return fail(c, MIRGE_E_ARG, "FASTQ device buffer must be 16-byte aligned");
     kt_clear(c, "fastq");
     const uint64_t FQ_WINDOW = fq_window();
-    HIPCHK(c, c->ctr.ensure(64, false, 0, c->st));
+    HIPCHK(c, c->ctr.ensure(128, false, 0, c->st));
     uint64_t newlines = 0;
     std::vector<uint64_t> win_nl;
     const uint32_t max_seg = (uint32_t)(FQ_WINDOW / FQ_SEG);
@@ -726,6 +803,7 @@ int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t la
     HIPCHK(c, c->stage16.ensure(std::max<uint64_t>(n, 1) * 16, false, 0, c->st));
     HIPCHK(c, c->stage48.ensure(std::max<uint64_t>(n, 1) * 48, false, 0, c->st));
     HIPCHK(c, hipMemsetAsync(c->fq_start.p, 0xFF, std::max<uint64_t>(n, 1) * 8, c->st));
+    HIPCHK(c, c->fq_odd.ensure(std::max<uint64_t>(n, 1) * 8, false, 0, c->st));
     uint64_t *d_qs = nullptr, *d_qe = nullptr;
     if (tp) {
         HIPCHK(c, c->fq_qstart.ensure(std::max<uint64_t>(n, 1) * 8, false, 0, c->st));
@@ -734,7 +812,7 @@ int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t la
         HIPCHK(c, hipMemsetAsync(c->fq_qend.p, 0xFF, std::max<uint64_t>(n, 1) * 8, c->st));
         d_qs = c->fq_qstart.as<uint64_t>(); d_qe = c->fq_qend.as<uint64_t>();
     }
-    HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 64, c->st));
+    HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 128, c->st));
     // pass 2 per window: record starts.  Single-window files reuse the scan of pass 1.
     kt_begin(c, "fastq_index");
     uint64_t o0 = 0; size_t wi = 0;
@@ -762,22 +840,37 @@ int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t la
         kt_begin(c, "fastq_trim");
         hipLaunchKernelGGL(k_fq_trim_pack, dim3((uint32_t)((n + TRIM_BLOCK - 1) / TRIM_BLOCK)), dim3(TRIM_BLOCK), 0, c->st, d, size,
                            c->fq_start.as<uint64_t>(), d_qs, d_qe, n, tp->dev, c->stage16.as<uint64_t>(), c->stage48.as<uint64_t>(),
-                           c->ctr.as<unsigned long long>());
+                           c->fq_odd.as<uint64_t>(), c->ctr.as<unsigned long long>());
         kt_end(c, "fastq_trim", size);
         HIPCHK(c, hipGetLastError());
     } else if (n) {
         kt_begin(c, "fastq_pack");
         hipLaunchKernelGGL(k_fq_pack, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->st, d, size, c->fq_start.as<uint64_t>(), n,
-                           c->stage16.as<uint64_t>(), c->stage48.as<uint64_t>(), c->ctr.as<unsigned long long>());
+                           c->stage16.as<uint64_t>(), c->stage48.as<uint64_t>(), c->fq_odd.as<uint64_t>(), c->ctr.as<unsigned long long>());
         kt_end(c, "fastq_pack", n * 24 + size / 4);
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 40, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 72, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     if (tp) tp->kept = c->h_ctr[4];
     if (c->h_ctr[2] == 6) return fail(c, MIRGE_E_FORMAT, "record " + std::to_string(c->h_ctr[3]) + ": sequence and quality lines differ in length");
-    if (c->h_ctr[2] == 4) return fail(c, MIRGE_E_FORMAT, "read " + std::to_string(c->h_ctr[3]) + " holds a character other than A, C, G, T, N");
-    if (c->h_ctr[2] == 5) return fail(c, MIRGE_E_LIMIT, "read " + std::to_string(c->h_ctr[3]) + " is longer than " + std::to_string(MIRGE_MAX_READ_LEN) + " nt");
+    if (c->h_ctr[2] == 4 || c->h_ctr[2] == 5) return verb_refused(c, (int)c->h_ctr[2], c->h_ctr[3]);
+    if (const uint64_t m = c->h_ctr[7]) {
+        // reads no key holds: their bytes come back in one pool and join the verbatim table
+        const uint64_t nbytes = c->h_ctr[8];
+        HIPCHK(c, c->fq_oddtab.ensure(m * 8 + 8, false, 0, c->st));
+        HIPCHK(c, c->fq_oddpool.ensure(nbytes + 8, false, 0, c->st));
+        unsigned long long* cursor = c->fq_oddtab.as<unsigned long long>() + m;
+        HIPCHK(c, hipMemsetAsync(cursor, 0, 8, c->st));
+        hipLaunchKernelGGL(k_fq_odd_gather, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, c->st, d, c->fq_start.as<uint64_t>(),
+                           c->fq_odd.as<uint64_t>(), m, c->fq_oddpool.as<uint8_t>(), c->fq_oddtab.as<uint64_t>(), cursor);
+        HIPCHK(c, hipGetLastError());
+        std::vector<uint64_t> tab((size_t)m); std::vector<char> pool((size_t)nbytes + 1);
+        HIPCHK(c, hipMemcpyAsync(tab.data(), c->fq_oddtab.p, m * 8, hipMemcpyDeviceToHost, c->st));
+        if (nbytes) HIPCHK(c, hipMemcpyAsync(pool.data(), c->fq_oddpool.p, nbytes, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        for (uint64_t j = 0; j < m; ++j) c->vb.add(pool.data() + (tab[(size_t)j] >> 16), (size_t)(tab[(size_t)j] & 0xFFFF), sample, c->S, 1);
+    }
     uint64_t n16 = c->h_ctr[0], n48 = c->h_ctr[1];
     return collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
 }
@@ -1077,6 +1170,51 @@ int counts_class(mirge_ctx* c, Class& C, int M) {
     return MIRGE_OK;
 }
 
+// the verbatim uniques: pool of packed records up, every round, their share of the count vectors (on st2, behind the
+// 48-byte class)
+int annotate_verb(mirge_ctx* c) {
+    Verb& V = c->vb;
+    const uint64_t U = V.seq.size(), E = V.coo_u.size();
+    if (U == 0) return MIRGE_OK;
+    hipStream_t st = c->st2;
+    std::vector<uint64_t> off((size_t)U); std::vector<uint32_t> len((size_t)U);
+    uint64_t words = 0;
+    for (uint64_t u = 0; u < U; ++u) { off[(size_t)u] = words; len[(size_t)u] = (uint32_t)V.seq[(size_t)u].size(); words += (uint64_t)verb_words((int)len[(size_t)u]); }
+    std::vector<uint64_t> pool((size_t)words);
+    parallel_slices(U, host_threads(), [&](uint64_t lo, uint64_t hi, int) {
+        for (uint64_t u = lo; u < hi; ++u) verb_pack(V.seq[(size_t)u].data(), (int)len[(size_t)u], pool.data() + off[(size_t)u]);
+    });
+    HIPCHK(c, V.pool.ensure(words * 8, false, 0, st)); HIPCHK(c, V.off.ensure(U * 8, false, 0, st)); HIPCHK(c, V.len.ensure(U * 4, false, 0, st));
+    HIPCHK(c, V.ann_round.ensure(U, false, 0, st)); HIPCHK(c, V.ann_ref.ensure(U * 4, false, 0, st)); HIPCHK(c, V.ann_amb.ensure(U, false, 0, st));
+    HIPCHK(c, V.d_u.ensure(E * 4 + 4, false, 0, st)); HIPCHK(c, V.d_s.ensure(E * 4 + 4, false, 0, st)); HIPCHK(c, V.d_c.ensure(E * 4 + 4, false, 0, st));
+    HIPCHK(c, hipMemcpyAsync(V.pool.p, pool.data(), words * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(V.off.p, off.data(), U * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(V.len.p, len.data(), U * 4, hipMemcpyHostToDevice, st));
+    if (E) {
+        HIPCHK(c, hipMemcpyAsync(V.d_u.p, V.coo_u.data(), E * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(V.d_s.p, V.coo_s.data(), E * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(V.d_c.p, V.coo_c.data(), E * 4, hipMemcpyHostToDevice, st));
+    }
+    uint32_t round_libs = 0;
+    for (int r = 0; r < c->n_rounds; ++r) round_libs |= (uint32_t)(c->rounds[r].lib & 3) << (2 * r);
+    const uint32_t iscan_rounds = c->rounds[0].lib == MIRGE_LIB_MIRNA ? 1u : 0u;
+    for (int r = 0; r < c->n_rounds; ++r) {
+        const mirge_round& R = c->rounds[r];
+        RoundDev P{R.lib, R.len_lt, R.len_gt, R.trim5, R.trim3, R.seedlen, R.seedmm, R.maxmm};
+        hipLaunchKernelGGL(k_match_verb, dim3((uint32_t)((U + 255) / 256)), dim3(256), 0, st, V.pool.as<uint64_t>(), V.off.as<uint64_t>(),
+                           V.len.as<uint32_t>(), (uint32_t)U, V.ann_round.as<uint8_t>(), V.ann_ref.as<int32_t>(), V.ann_amb.as<uint8_t>(),
+                           c->libs[R.lib].dev(), P, r, c->d_stats + (size_t)r * STAT_WORDS);
+    }
+    if (E)
+        hipLaunchKernelGGL(k_counts_verb, dim3((uint32_t)((E + 255) / 256)), dim3(256), 0, st, V.d_u.as<uint32_t>(), V.d_s.as<uint32_t>(),
+                           V.d_c.as<uint32_t>(), (uint32_t)E, c->S, V.len.as<uint32_t>(), V.ann_round.as<uint8_t>(), V.ann_ref.as<int32_t>(),
+                           round_libs, iscan_rounds, LEN_BINS, c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu);
+    HIPCHK(c, hipGetLastError());
+    // pool / off / len are host vectors of this frame: the copies must have left them
+    HIPCHK(c, hipStreamSynchronize(st));
+    return MIRGE_OK;
+}
+
 static const char* kRoundNames[MIRGE_MAX_ROUNDS] = {"match_round1", "match_round2", "match_round3", "match_round4",
                                                     "match_round5", "match_round6", "match_round7", "match_round8"};
 
@@ -1106,7 +1244,7 @@ int annotate(mirge_ctx* c) {
     }
     int M = (int)c->libs[MIRGE_LIB_MIRNA].names.size(), S = c->S;
     size_t qn = std::max<size_t>((size_t)M * S, 1);
-    const size_t w_stats = MIRGE_MAX_ROUNDS * STAT_WORDS, w_cat = (size_t)5 * S, w_len = (size_t)128 * S, w_tu = (size_t)S;
+    const size_t w_stats = MIRGE_MAX_ROUNDS * STAT_WORDS, w_cat = (size_t)5 * S, w_len = (size_t)LEN_BINS * S, w_tu = (size_t)S;
     const size_t w_out = w_stats + 2 * qn + w_cat + w_len + w_tu, w_all = w_out + 2 * (MIRGE_MAX_ROUNDS + 1) + MIRGE_MAX_ROUNDS;
     HIPCHK(c, c->state.ensure(w_all * 8, false, 0, c->st));
     if (c->h_state_cap < w_out) {
@@ -1138,6 +1276,7 @@ int annotate(mirge_ctx* c) {
     int rc = counts_class<2>(c, c->cls[0], M);
     kt_end(c, "counts", (c->cls[0].coo_n + c->cls[1].coo_n) * 8 + (uint64_t)16 * M * S);
     if (!rc) rc = counts_class<6>(c, c->cls[1], M);
+    if (!rc) rc = annotate_verb(c);
     if (rc) return rc;
     { int rj = join_st2(c); if (rj) return rj; }
     HIPCHK(c, hipEventRecord(e2, c->st));
@@ -1178,12 +1317,28 @@ int annotate(mirge_ctx* c) {
 void decode_key(const uint64_t* k, int KW, char* out, int* len_out) {
     int SW = KW == 2 ? 2 : 4;
     int len = (int)(k[SW - 1] >> 56);
+    if (len > (KW == 2 ? 56 : 124)) len = KW == 2 ? 56 : 124;      // keys handed in by the caller are trusted, but never past the buffer
     for (int i = 0; i < len; ++i) {
         int code = (int)((k[i >> 5] >> (2 * (i & 31))) & 3);
         bool isN = KW == 6 && ((k[4 + (i >> 6)] >> (i & 63)) & 1);
         out[i] = isN ? 'N' : "ACGT"[code];
     }
     *len_out = len;
+}
+
+// unique i of the table -> class (0 / 1 keys, 2 verbatim) and index inside it
+inline int unique_class(const mirge_ctx* c, uint64_t i, uint64_t& j) {
+    const uint64_t U0 = c->cls[0].U, U1 = c->cls[1].U;
+    if (i < U0) { j = i; return 0; }
+    if (i < U0 + U1) { j = i - U0; return 1; }
+    j = i - U0 - U1; return 2;
+}
+// its sequence (after fetch_host)
+inline void unique_seq(const mirge_ctx* c, int k, uint64_t j, std::string& out) {
+    if (k == 2) { out = c->vb.seq[(size_t)j]; return; }
+    char buf[128]; int len = 0;
+    decode_key(&c->h_keys[k][(size_t)j * (k ? 6 : 2)], k ? 6 : 2, buf, &len);
+    out.assign(buf, (size_t)len);
 }
 
 int fetch_host(mirge_ctx* c) {
@@ -1207,11 +1362,22 @@ int fetch_host(mirge_ctx* c) {
             HIPCHK(c, hipMemcpyAsync(c->h_coo_c[k].data(), C.coo_c.p, (size_t)C.coo_n * 4, hipMemcpyDeviceToHost, c->st));
         }
     }
+    {
+        Verb& V = c->vb;
+        const size_t UV = V.seq.size();
+        c->h_round[2].assign(UV, 0); c->h_ref[2].assign(UV, -1); c->h_amb[2].assign(UV, 0);
+        if (UV && c->annotated) {
+            HIPCHK(c, hipMemcpyAsync(c->h_round[2].data(), V.ann_round.p, UV, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipMemcpyAsync(c->h_ref[2].data(), V.ann_ref.p, UV * 4, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipMemcpyAsync(c->h_amb[2].data(), V.ann_amb.p, UV, hipMemcpyDeviceToHost, c->st));
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->st));
-    // CSR unique -> (sample, count)
-    uint64_t U0 = c->cls[0].U, U = U0 + c->cls[1].U;
+    // CSR unique -> (sample, count); uniques are numbered [16-byte class | 48-byte class | verbatim]
+    uint64_t U0 = c->cls[0].U, UK = U0 + c->cls[1].U, U = UK + c->vb.seq.size();
     c->csr_off.assign((size_t)U + 1, 0);
     for (int k = 0; k < 2; ++k) for (auto g : c->h_coo_g[k]) c->csr_off[(size_t)(g + (k ? U0 : 0)) + 1]++;
+    for (auto g : c->vb.coo_u) c->csr_off[(size_t)(UK + g) + 1]++;
     for (uint64_t u = 0; u < U; ++u) c->csr_off[(size_t)u + 1] += c->csr_off[(size_t)u];
     uint64_t tot = c->csr_off[(size_t)U];
     c->csr_sample.assign((size_t)tot, 0); c->csr_count.assign((size_t)tot, 0);
@@ -1223,6 +1389,10 @@ int fetch_host(mirge_ctx* c) {
                 uint64_t at = cur[(size_t)u]++;
                 c->csr_sample[(size_t)at] = (uint32_t)sg.sample; c->csr_count[(size_t)at] = c->h_coo_c[k][(size_t)e];
             }
+    for (size_t e = 0; e < c->vb.coo_u.size(); ++e) {
+        uint64_t at = cur[(size_t)(UK + c->vb.coo_u[e])]++;
+        c->csr_sample[(size_t)at] = c->vb.coo_s[e]; c->csr_count[(size_t)at] = c->vb.coo_c[e];
+    }
     c->host_valid = true;
     return MIRGE_OK;
 }
@@ -1301,7 +1471,8 @@ void mirge_close(mirge_ctx* c) {
     if (c->st2) (void)hipStreamSynchronize(c->st2);
     for (auto& L : c->libs) L.release();
     for (auto& C : c->cls) C.release();
-    DevBuf* ws[] = {&c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
+    c->vb.release();
+    DevBuf* ws[] = {&c->fq_odd, &c->fq_oddtab, &c->fq_oddpool, &c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
                     &c->fq_raw, &c->fq_seg, &c->fq_segb, &c->fq_start, &c->fq_qstart, &c->fq_qend, &c->sh_ctr, &c->sh_w[0], &c->sh_w[1], &c->hist, &c->off_tmp, &c->state};
     for (auto* b : ws) b->release();
     for (auto& k : c->kt) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
@@ -1322,6 +1493,7 @@ int32_t mirge_reset(mirge_ctx* c, int32_t n_samples) {
     HIPCHK(c, hipSetDevice(c->device));
     c->S = n_samples;
     for (auto& C : c->cls) C.reset();
+    c->vb.reset();
     c->annotated = false; c->counts_valid = false; c->host_valid = false;
     return MIRGE_OK;
 }
@@ -1457,12 +1629,51 @@ int32_t mirge_shard_import(mirge_ctx* c, const void* d_rec16, uint64_t n16, cons
     return shard_import(c, d_rec16, n16, d_rec48, n48);
 }
 
+// verbatim uniques across ranks: a byte blob of [len u32 | sample u32 | count u32 | len bytes] per entry, host memory
+uint64_t mirge_verb_export_size(const mirge_ctx* c) {
+    if (!c) return 0;
+    uint64_t n = 0;
+    for (size_t e = 0; e < c->vb.coo_u.size(); ++e) n += 12 + c->vb.seq[c->vb.coo_u[e]].size();
+    return n;
+}
+int32_t mirge_verb_export(mirge_ctx* c, void* blob) {
+    if (!c || (!blob && mirge_verb_export_size(c))) return c ? fail(c, MIRGE_E_ARG, "null buffer") : MIRGE_E_ARG;
+    uint8_t* o = (uint8_t*)blob;
+    for (size_t e = 0; e < c->vb.coo_u.size(); ++e) {
+        const std::string& q = c->vb.seq[c->vb.coo_u[e]];
+        const uint32_t h[3] = {(uint32_t)q.size(), c->vb.coo_s[e], c->vb.coo_c[e]};
+        memcpy(o, h, 12); memcpy(o + 12, q.data(), q.size()); o += 12 + q.size();
+    }
+    return MIRGE_OK;
+}
+int32_t mirge_verb_clear(mirge_ctx* c) {
+    if (!c) return MIRGE_E_ARG;
+    c->vb.reset(); c->annotated = false; c->counts_valid = false; c->host_valid = false;
+    return MIRGE_OK;
+}
+int32_t mirge_verb_import(mirge_ctx* c, const void* blob, uint64_t nbytes, int32_t rank, int32_t world) {
+    if (!c || (nbytes && !blob) || world < 1 || rank < 0 || rank >= world) return c ? fail(c, MIRGE_E_ARG, "bad arguments") : MIRGE_E_ARG;
+    const uint8_t* p = (const uint8_t*)blob; const uint8_t* end = p + nbytes;
+    while (p < end) {
+        uint32_t h[3];
+        if (end - p < 12) return fail(c, MIRGE_E_FORMAT, "truncated verbatim-read blob");
+        memcpy(h, p, 12); p += 12;
+        if ((uint64_t)(end - p) < h[0] || h[0] > MIRGE_MAX_READ_LEN || (int)h[1] >= c->S) return fail(c, MIRGE_E_FORMAT, "corrupt verbatim-read blob");
+        uint64_t f = 1469598103934665603ull;
+        for (uint32_t i = 0; i < h[0]; ++i) { f ^= p[i]; f *= 1099511628211ull; }
+        if ((int32_t)((f >> 17) % (uint64_t)world) == rank) c->vb.add((const char*)p, h[0], (int)h[1], c->S, h[2]);
+        p += h[0];
+    }
+    c->annotated = false; c->counts_valid = false; c->host_valid = false;
+    return MIRGE_OK;
+}
+
 int32_t mirge_pack_dev(mirge_ctx* c, const void* d_seqs, uint32_t width, const void* d_lens, uint64_t n,
                        void* d_keys16, uint64_t* n16, void* d_keys48, uint64_t* n48) {
     if (!c || (n && (!d_seqs || !d_lens || !d_keys16 || !d_keys48))) return c ? fail(c, MIRGE_E_ARG, "null device pointer") : MIRGE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, c->ctr.ensure(64, false, 0, c->st));
-    HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 64, c->st));
+    HIPCHK(c, c->ctr.ensure(128, false, 0, c->st));
+    HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 128, c->st));
     c->h_ctr[0] = c->h_ctr[1] = 0;
     int rc = pack_launch(c, d_seqs, width, d_lens, n, d_keys16, d_keys48);
     if (rc) return rc;
@@ -1584,13 +1795,12 @@ int32_t mirge_counts_flat_set(mirge_ctx* c, const uint64_t* in) {
 __global__ void __launch_bounds__(256)
 k_flat_pack(const unsigned long long* __restrict__ arena, uint64_t w_stats, uint64_t qn2, uint64_t w_cat, uint64_t S, int n_rounds,
             unsigned long long* __restrict__ out) {
-    // arena: [round stats | quant | iscan | categories | 128 x S length histogram | trimmedUniq]; out: the flat layout
+    // arena: [round stats | quant | iscan | categories | LEN_BINS x S length histogram | trimmedUniq]; out: the flat layout
     const uint64_t n_len = (uint64_t)(MIRGE_MAX_READ_LEN + 1) * S, head = qn2 + w_cat;
     const uint64_t total = head + n_len + S + 2 * MIRGE_MAX_ROUNDS;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         unsigned long long v = 0;
-        if (i < head + n_len) v = arena[w_stats + i];
-        else if (i < head + n_len + S) v = arena[w_stats + head + 128 * S + (i - head - n_len)];
+        if (i < head + n_len + S) v = arena[w_stats + i];
         else {
             const uint64_t j = i - head - n_len - S;                 // j < MAX_ROUNDS: processed, else aligned
             const int r = (int)(j % MIRGE_MAX_ROUNDS), w = (int)(j / MIRGE_MAX_ROUNDS);
@@ -1621,28 +1831,30 @@ int32_t mirge_counts_flat_set_dev(mirge_ctx* c, const void* d_in) {
     return mirge_counts_flat_set(c, h.data());
 }
 
-uint64_t mirge_n_unique(const mirge_ctx* c) { return c ? c->cls[0].U + c->cls[1].U : 0; }
+uint64_t mirge_n_unique(const mirge_ctx* c) { return c ? c->cls[0].U + c->cls[1].U + c->vb.seq.size() : 0; }
+uint32_t mirge_max_unique_len(const mirge_ctx* c) {
+    if (!c) return 0;
+    return std::max<uint32_t>(c->vb.maxlen, c->cls[1].U ? (uint32_t)KeyTraits<6>::MAXLEN : (uint32_t)KeyTraits<2>::MAXLEN);
+}
 
-int32_t mirge_export_uniques(mirge_ctx* c, char* seqs, uint32_t stride, uint8_t* lens, int8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb) {
+int32_t mirge_export_uniques(mirge_ctx* c, char* seqs, uint32_t stride, uint16_t* lens, int8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb) {
     if (!c) return MIRGE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = fetch_host(c);
     if (rc) return rc;
-    uint64_t u = 0;
-    for (int k = 0; k < 2; ++k) {
-        int KW = k == 0 ? 2 : 6;
-        for (uint64_t i = 0; i < c->cls[k].U; ++i, ++u) {
-            char buf[128]; int len = 0;
-            if (seqs || lens) decode_key(&c->h_keys[k][(size_t)i * KW], KW, buf, &len);
-            if (seqs) {
-                if ((uint32_t)len > stride) return fail(c, MIRGE_E_ARG, "stride smaller than a unique sequence");
-                memset(seqs + u * stride, 0, stride); memcpy(seqs + u * stride, buf, (size_t)len);
-            }
-            if (lens) lens[u] = (uint8_t)len;
-            if (ann_round) ann_round[u] = (int8_t)c->h_round[k][(size_t)i];
-            if (ann_ref) ann_ref[u] = c->h_ref[k][(size_t)i];
-            if (ann_amb) ann_amb[u] = c->h_amb[k][(size_t)i];
+    const uint64_t U = mirge_n_unique(c);
+    std::string sq;
+    for (uint64_t u = 0; u < U; ++u) {
+        uint64_t i; const int k = unique_class(c, u, i);
+        if (seqs || lens) unique_seq(c, k, i, sq);
+        if (seqs) {
+            if (sq.size() > stride) return fail(c, MIRGE_E_ARG, "stride smaller than a unique sequence (mirge_max_unique_len)");
+            memset(seqs + u * stride, 0, stride); memcpy(seqs + u * stride, sq.data(), sq.size());
         }
+        if (lens) lens[u] = (uint16_t)sq.size();
+        if (ann_round) ann_round[u] = (int8_t)c->h_round[k][(size_t)i];
+        if (ann_ref) ann_ref[u] = c->h_ref[k][(size_t)i];
+        if (ann_amb) ann_amb[u] = c->h_amb[k][(size_t)i];
     }
     return MIRGE_OK;
 }
@@ -1652,12 +1864,9 @@ int32_t mirge_unique(mirge_ctx* c, uint64_t i, const char** seq, int32_t ref_idx
     HIPCHK(c, hipSetDevice(c->device));
     int rc = fetch_host(c);
     if (rc) return rc;
-    uint64_t U0 = c->cls[0].U;
-    if (i >= U0 + c->cls[1].U) return fail(c, MIRGE_E_ARG, "unique index out of range");
-    int k = i < U0 ? 0 : 1; uint64_t j = k ? i - U0 : i; int KW = k ? 6 : 2;
-    char buf[128]; int len = 0;
-    decode_key(&c->h_keys[k][(size_t)j * KW], KW, buf, &len);
-    c->uniq_seq.assign(buf, (size_t)len);
+    if (i >= mirge_n_unique(c)) return fail(c, MIRGE_E_ARG, "unique index out of range");
+    uint64_t j; const int k = unique_class(c, i, j);
+    unique_seq(c, k, j, c->uniq_seq);
     if (seq) *seq = c->uniq_seq.c_str();
     int r = c->h_round[k][(size_t)j];
     if (ref_idx) { for (int q = 0; q < MIRGE_MAX_ROUNDS; ++q) ref_idx[q] = -1; if (r > 0) ref_idx[r - 1] = c->h_ref[k][(size_t)j]; }
@@ -1747,17 +1956,15 @@ int32_t mirge_write_tables(mirge_ctx* c, const char* merges_csv, const char* out
         return fail(c, MIRGE_E_IO, "cannot write the tables into " + dir);
     }
     fputs(head.c_str(), fm); fputs(head.c_str(), fu);
-    const uint64_t U0 = c->cls[0].U, U = U0 + c->cls[1].U;
+    const uint64_t U = mirge_n_unique(c);
     std::vector<uint64_t> cnt((size_t)S);
     std::string row;
     for (uint64_t u = 0; u < U; ++u) {
-        const int k = u < U0 ? 0 : 1; const uint64_t j = k ? u - U0 : u; const int KW = k ? 6 : 2;
-        char buf[128]; int len = 0;
-        decode_key(&c->h_keys[k][(size_t)j * KW], KW, buf, &len);
+        uint64_t j; const int k = unique_class(c, u, j);
         const int r = c->h_round[k][(size_t)j];
         std::fill(cnt.begin(), cnt.end(), 0);
         for (uint64_t e = c->csr_off[(size_t)u]; e < c->csr_off[(size_t)u + 1]; ++e) cnt[c->csr_sample[(size_t)e]] += c->csr_count[(size_t)e];
-        row.assign(buf, (size_t)len);
+        unique_seq(c, k, j, row);
         row += r > 0 ? ",1" : ",0";
         for (int q = 1; q <= 5; ++q) { row += ","; if (q == r) row += c->libs[c->rounds[q - 1].lib].short_names[(size_t)c->h_ref[k][(size_t)j]]; }
         for (int i = 0; i < S; ++i) { row += ","; row += std::to_string(cnt[(size_t)i]); }
@@ -1786,14 +1993,14 @@ int32_t mirge_write_tables(mirge_ctx* c, const char* merges_csv, const char* out
     return bad ? fail(c, MIRGE_E_IO, "short write in " + dir) : MIRGE_OK;
 }
 
-uint64_t mirge_n_counts(const mirge_ctx* c) { return c ? c->cls[0].coo_n + c->cls[1].coo_n : 0; }
+uint64_t mirge_n_counts(const mirge_ctx* c) { return c ? c->cls[0].coo_n + c->cls[1].coo_n + c->vb.coo_u.size() : 0; }
 
 int32_t mirge_export_counts(mirge_ctx* c, uint64_t* uid, uint32_t* sample, uint32_t* count) {
     if (!c) return MIRGE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = fetch_host(c);
     if (rc) return rc;
-    uint64_t U = c->cls[0].U + c->cls[1].U, o = 0;
+    uint64_t U = mirge_n_unique(c), o = 0;
     for (uint64_t u = 0; u < U; ++u)
         for (uint64_t e = c->csr_off[(size_t)u]; e < c->csr_off[(size_t)u + 1]; ++e, ++o) {
             if (uid) uid[o] = u;

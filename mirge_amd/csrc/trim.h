@@ -75,6 +75,19 @@ inline int trim_dev_from_spec(const char* adapter, int trim5, int trim3, TrimDev
 
 MG_HD int code_at(const uint64_t (&sq)[4], int j) { return (int)((pick<4>(sq, j >> 5) >> (2 * (j & 31))) & 3); }
 MG_HD bool isn_at(const uint64_t (&nm)[2], int j) { return ((j < 64 ? nm[0] : nm[1]) >> (j & 63)) & 1; }
+// How the adapter aligner sees a read: a 2-bit code and "matches nothing" per position.  PackedAcc: a read held as key
+// words (<= 124 nt of A C G T N).  ByteAcc: the sequence line where it lies in the file -- lines no key holds (longer,
+// or with other characters: those match no adapter base, as N does; cutadapt compares the bytes).
+struct PackedAcc {
+    const uint64_t (&sq)[4]; const uint64_t (&nm)[2];
+    MG_HD int code(int j) const { return code_at(sq, j); }
+    MG_HD bool isn(int j) const { return isn_at(nm, j); }
+};
+struct ByteAcc {
+    const uint8_t* __restrict__ line;
+    MG_HD int code(int j) const { const int c = base_code(line[j]); return c < 0 || c > 3 ? 0 : c; }
+    MG_HD bool isn(int j) const { const int c = base_code(line[j]); return c < 0 || c > 3; }
+};
 
 // DP cell: cost (bits 24-31) | matches (16-23) | origin (0-15)
 MG_HD uint32_t cell(int cost, int matches, int origin) { return ((uint32_t)cost << 24) | ((uint32_t)matches << 16) | (uint32_t)origin; }
@@ -84,7 +97,8 @@ MG_HD int c_origin(uint32_t c) { return (int)(c & 0xFFFF); }
 
 // Adapter `ad` against read nts [a, b): true if it matches; rstart (relative to a) and matches out.
 // col: this lane's DP column, cell i at col[i * stride].
-MG_HD bool adapter_match(const TrimDev& T, int ad, const uint64_t (&sq)[4], const uint64_t (&nm)[2], int a, int b,
+template <class Acc>
+MG_HD bool adapter_match(const TrimDev& T, int ad, const Acc& rd, int a, int b,
                          uint32_t* col, int stride, int& rstart, int& matches_out) {
     const int m = T.alen[ad], n = b - a;
     const uint64_t ac = T.acode[ad];
@@ -93,8 +107,8 @@ MG_HD bool adapter_match(const TrimDev& T, int ad, const uint64_t (&sq)[4], cons
         const uint64_t full = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1);
         uint64_t h = 0; int nrun = 0;                        // nrun: nts since the last N
         for (int j = 0; j < n; ++j) {
-            const int c = code_at(sq, a + j);
-            const bool isn = isn_at(nm, a + j);
+            const int c = rd.code(a + j);
+            const bool isn = rd.isn(a + j);
             h = ((h >> 2) | ((uint64_t)c << (2 * (m - 1)))) & full;
             nrun = isn ? 0 : nrun + 1;
             if (j >= m - 1 && nrun >= m && h == ac) { rstart = j - m + 1; matches_out = m; return true; }
@@ -106,8 +120,8 @@ MG_HD bool adapter_match(const TrimDev& T, int ad, const uint64_t (&sq)[4], cons
     int last = m < k + 1 ? m : k + 1;
     bool done = false;
     for (int j = 1; j <= n && !done; ++j) {
-        const int cj = code_at(sq, a + j - 1);
-        const bool nj = isn_at(nm, a + j - 1);
+        const int cj = rd.code(a + j - 1);
+        const bool nj = rd.isn(a + j - 1);
         uint32_t tmp = col[0];
         uint32_t up = cell(0, 0, j);                          // column[0]: cost 0, origin j
         col[0] = up;
@@ -174,18 +188,10 @@ MG_HD void quality_trim(const uint8_t* __restrict__ data, uint64_t qs, int n, in
     if (start >= stop) { start = 0; stop = 0; }
 }
 
-// One record.  s / qs / qe: offsets of its sequence line, quality line and the end of the quality line.
-// returns 0 = dropped (too short), 1 = kept (key words + len out), or an error code: 4 bad character,
-// 5 longer than 124 nt, 6 sequence and quality lines differ in length.
-MG_HD int trim_record(const uint8_t* __restrict__ data, uint64_t size, uint64_t s, uint64_t qs, uint64_t qe, const TrimDev& T,
-                      uint32_t* col, int stride, uint64_t (&ks)[4], uint64_t (&kn)[2], int& klen) {
-    uint64_t sq[4], nm[2]; int len; bool hasN;
-    int rc = fq_pack_read<true>(data, size, s, sq, nm, len, hasN);
-    if (rc) return rc;
-    if (qe > qs && data[qe - 1] == '\r') --qe;                 // cutadapt's FastqReader strips line ends
-    if ((int)(qe - qs) != len) return 6;
-    int a, b;
-    quality_trim(data, qs, len, T.base, a, b);
+// the trimming steps on read positions [a, b) after the quality trimmer: adapter or unconditional cut, the length
+// filter, then trim5 / trim3.  false = dropped.
+template <class Acc>
+MG_HD bool trim_steps(const TrimDev& T, const Acc& rd, uint32_t* col, int stride, int& a, int& b) {
     if (T.mode == 2) {
         if (T.uncond > 0) a = a + T.uncond < b ? a + T.uncond : b;
         else if (T.uncond < 0) b = b + T.uncond > a ? b + T.uncond : a;
@@ -193,26 +199,64 @@ MG_HD int trim_record(const uint8_t* __restrict__ data, uint64_t size, uint64_t 
         int best_matches = -1, best_rstart = -1;
         for (int ad = 0; ad < T.n_ad; ++ad) {
             int rs = 0, mt = 0;
-            if (adapter_match(T, ad, sq, nm, a, b, col, stride, rs, mt) && mt > best_matches) { best_matches = mt; best_rstart = rs; }
+            if (adapter_match(T, ad, rd, a, b, col, stride, rs, mt) && mt > best_matches) { best_matches = mt; best_rstart = rs; }
         }
         if (best_rstart >= 0) b = a + best_rstart;
     }
-    if (b - a < T.min_len) return 0;
+    if (b - a < T.min_len) return false;
     if (T.trim5 > 0) a = a + T.trim5 < b ? a + T.trim5 : b;
     if (T.trim3 > 0) b = b - T.trim3 > a ? b - T.trim3 : a;
+    return true;
+}
+
+// One record.  s / qs / qe: offsets of its sequence line, quality line and the end of the quality line.
+// returns 0 = dropped (too short), 1 = kept as a key (key words + len out), 2 = kept as a verbatim read (what is left
+// of it, [oa, ob) of the sequence line, fits no key), or an error code: 4 control character, 5 line longer than
+// FQ_MAX_LINE, 6 sequence and quality lines differ in length.
+MG_HD int trim_record(const uint8_t* __restrict__ data, uint64_t size, uint64_t s, uint64_t qs, uint64_t qe, const TrimDev& T,
+                      uint32_t* col, int stride, uint64_t (&ks)[4], uint64_t (&kn)[2], int& klen, int& oa, int& ob) {
+    uint64_t sq[4], nm[2]; int len; bool hasN;
+    int rc = fq_pack_read<true>(data, size, s, sq, nm, len, hasN);
+    if (qe > qs && data[qe - 1] == '\r') --qe;                 // cutadapt's FastqReader strips line ends
+    int a, b;
+    if (rc == 0) {
+        if ((int)(qe - qs) != len) return 6;
+        quality_trim(data, qs, len, T.base, a, b);
+        if (!trim_steps(T, PackedAcc{sq, nm}, col, stride, a, b)) return 0;
+        klen = b - a;
+        shr<4>(sq, 2 * a, ks); keep_low<4>(ks, 2 * klen);
+        shr<2>(nm, a, kn); keep_low<2>(kn, klen);
+        return 1;
+    }
+    // the raw line fits no key (150-nt reads with the adapter still on, lower case, IUPAC codes ...): the same steps on
+    // its bytes; what is left is packed if it fits a key by then
+    rc = fq_line_scan<true>(data, size, s, len);
+    if (rc) return rc;
+    if ((int)(qe - qs) != len) return 6;
+    quality_trim(data, qs, len, T.base, a, b);
+    if (!trim_steps(T, ByteAcc{data + s}, col, stride, a, b)) return 0;
     klen = b - a;
-    shr<4>(sq, 2 * a, ks); keep_low<4>(ks, 2 * klen);
-    shr<2>(nm, a, kn); keep_low<2>(kn, klen);
+    bool fits = klen <= 124;
+    for (int j = a; j < b && fits; ++j) fits = base_code(data[s + j]) >= 0;
+    if (!fits) { oa = a; ob = b; return 2; }
+    ks[0] = ks[1] = ks[2] = ks[3] = 0; kn[0] = kn[1] = 0;
+    for (int j = 0; j < klen; ++j) {
+        const int c = base_code(data[s + a + j]);
+        const uint64_t cc = c < 4 ? (uint64_t)c : 0ull;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ks[q] |= (q == (j >> 5)) ? cc << (2 * (j & 31)) : 0ull;
+        if (c == 4) { if (j < 64) kn[0] |= 1ull << j; else kn[1] |= 1ull << (j - 64); }
+    }
     return 1;
 }
 
 #ifdef __HIPCC__
 constexpr int TRIM_BLOCK = 256;
-// counters: [0] n16, [1] n48, [2] error code, [3] first offending record, [4] records kept
+// counters: [0] n16, [1] n48, [2] error code, [3] first offending record, [4] records kept, [7] verbatim reads, [8] their bytes
 __global__ void __launch_bounds__(TRIM_BLOCK)
 k_fq_trim_pack(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* __restrict__ start, const uint64_t* __restrict__ qstart,
                const uint64_t* __restrict__ qend, uint64_t n, TrimDev T, uint64_t* __restrict__ k16, uint64_t* __restrict__ k48,
-               unsigned long long* counters) {
+               uint64_t* __restrict__ odd, unsigned long long* counters) {
     __shared__ uint32_t s_col[(TRIM_MAX_ALEN + 1) * TRIM_BLOCK];
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -220,14 +264,19 @@ k_fq_trim_pack(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* 
     if (s == FQ_NONE) s = size;
     if (qs == FQ_NONE) qs = size;
     if (qe == FQ_NONE) qe = size;
-    uint64_t ks[4], kn[2]; int len = 0;
-    int rc = trim_record(data, size, s, qs, qe, T, s_col + threadIdx.x, TRIM_BLOCK, ks, kn, len);
-    if (rc > 1) {
+    uint64_t ks[4], kn[2]; int len = 0, oa = 0, ob = 0;
+    int rc = trim_record(data, size, s, qs, qe, T, s_col + threadIdx.x, TRIM_BLOCK, ks, kn, len, oa, ob);
+    if (rc > 2) {
         if (atomicCAS(&counters[2], 0ull, (unsigned long long)rc) == 0ull) counters[3] = i;
         return;
     }
     if (rc == 0) return;
     atomicAdd(&counters[4], 1ull);
+    if (rc == 2) {
+        odd[atomicAdd(&counters[7], 1ull)] = fq_odd_entry(i, oa, ob - oa);
+        atomicAdd(&counters[8], (unsigned long long)(ob - oa));
+        return;
+    }
     if (!(kn[0] | kn[1]) && len <= 56) {
         unsigned long long p = atomicAdd(&counters[0], 1ull);
         k16[2 * p] = ks[0];

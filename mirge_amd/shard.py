@@ -63,7 +63,8 @@ def merge_uniques(ctx, dist, device):
     """All-to-all of the local unique tables by key owner.  ctx: capi.Context after its
     collapse calls; afterwards it holds exactly the sequences this rank owns, with counts summed over all
     ranks, ready for annotate().  Two collectives: the record counts, then the records (16-byte and
-    48-byte classes in one buffer each)."""
+    48-byte classes in one buffer each).  Verbatim uniques (reads no key holds: a host-side table) follow in an
+    all-gather of byte blobs -- only when some rank has any."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     on_gpu = device is not None and str(device).startswith("cuda")
@@ -74,11 +75,12 @@ def merge_uniques(ctx, dist, device):
     send16 = torch.empty(max(int(n16.sum()) * REC16, 8), dtype=torch.uint8, device=device)
     send48 = torch.empty(max(int(n48.sum()) * REC48, 8), dtype=torch.uint8, device=device)
     ctx.shard_export(world, send16.data_ptr(), send48.data_ptr())
-    mine = torch.tensor(np.stack([n16, n48], axis=1).astype(np.int64), device=wire)          # [world, 2]: what I send to each rank
+    blob = ctx.verb_export()
+    mine = torch.tensor(np.stack([n16, n48, np.full(world, len(blob))], axis=1).astype(np.int64), device=wire)   # [world, 3]: what I send to each rank (+ my blob size)
     theirs = torch.empty_like(mine)                                                           # what each rank sends to me
     dist.all_to_all_single(theirs, mine)
     r = theirs.cpu().numpy()
-    r16, r48 = r[:, 0], r[:, 1]
+    r16, r48, rblob = r[:, 0], r[:, 1], r[:, 2]
     if wire is not device:
         send16, send48 = send16.cpu(), send48.cpu()
     recv16 = torch.empty(max(int(r16.sum()) * REC16, 8), dtype=torch.uint8, device=wire)
@@ -92,4 +94,14 @@ def merge_uniques(ctx, dist, device):
     if on_gpu:
         torch.cuda.synchronize(device)
     ctx.shard_import(recv16.data_ptr(), int(r16.sum()), recv48.data_ptr(), int(r48.sum()))
+    if int(rblob.sum()):                     # every rank sees the same sizes: all of them take this branch, or none
+        cap = int(rblob.max())
+        pad = torch.zeros(cap, dtype=torch.uint8)
+        pad[:len(blob)] = torch.from_numpy(np.ascontiguousarray(blob))
+        pad = pad.to(wire) if wire is not None else pad
+        got = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(got, pad)
+        ctx.verb_clear()
+        for src in range(world):
+            ctx.verb_import(got[src][:int(rblob[src])].cpu().numpy(), rank, world)
     return int(r16.sum()) + int(r48.sum())

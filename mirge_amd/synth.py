@@ -374,10 +374,11 @@ ILLUMINA_ADAPTER = "TGGAATTCTCGGGTGCCAAGGAACTCCAG"      # reference miRge.pl:82
 
 
 def make_raw_fastq(seqs, lens, seed: int, adapter: str = ILLUMINA_ADAPTER, read_len: int = 50, phred: int = 33,
-                   adapter_error: float = 0.15, low_tail: float = 0.25, crlf: bool = False) -> bytes:
+                   adapter_error: float = 0.15, low_tail: float = 0.25, crlf: bool = False, odd: float = 0.0) -> bytes:
     """Raw reads as a sequencer writes them: insert + 3' adapter + random fill, cut to read_len.  A share
     of the reads carries one or two errors (substitution / insertion / deletion) in the adapter part, a share a
-    low-quality 3' tail, a few a low-quality base in the middle or an N.  Returns FASTQ text."""
+    low-quality 3' tail, a few a low-quality base in the middle or an N; a share `odd` is lower case, mixed case, or holds an IUPAC code or '.' (reads
+    no key holds).  Returns FASTQ text."""
     rng = np.random.default_rng(seed)
     acgt = "ACGT"
     hi, lo = chr(phred + 40), chr(phred + 2)
@@ -406,6 +407,14 @@ def make_raw_fastq(seqs, lens, seed: int, adapter: str = ILLUMINA_ADAPTER, read_
             q[int(rng.integers(0, len(r)))] = lo
         if rng.random() < 0.02:
             p = int(rng.integers(0, len(r))); r = r[:p] + "N" + r[p + 1:]
+        if odd and rng.random() < odd:
+            kind = rng.random()
+            if kind < 0.3:
+                r = r.lower()
+            elif kind < 0.5:
+                r = "".join(c.lower() if rng.random() < 0.5 else c for c in r)
+            else:
+                p = int(rng.integers(0, len(r))); r = r[:p] + str(rng.choice(list("RYKMSWBDHV.x"))) + r[p + 1:]
         out.append("@raw%d%s%s%s+%s%s%s" % (i, nl, r, nl, nl, "".join(q), nl))
     return "".join(out).encode()
 

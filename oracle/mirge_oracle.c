@@ -88,7 +88,7 @@ int64_t orc_lib_total_len(const orc_lib* L) { return (int64_t)L->offs[L->n]; }
 /* ------------------------------------------------------------- the policy */
 
 typedef struct {
-    char r[2][512];     /* [1] = trimmed read ('+'), [0] = its reverse complement ('-') */
+    char r[2][1024];    /* [1] = trimmed read ('+'), [0] = its reverse complement ('-') */
     int  l;             /* trimmed length */
     int  s;             /* seed length actually used: min(-l, l) */
     int  skip;          /* bowtie skips the read (empty after trimming, or l <= -n) */
@@ -99,13 +99,14 @@ typedef struct {
 static void query_init(orc_query* q, const char* read, int32_t len, const orc_round* P) {
     int l = len - P->trim5 - P->trim3;
     q->skip = 0;
-    if (l <= 0 || l > 500) { q->l = 0; q->s = 0; q->skip = 1; return; }
+    if (l <= 0 || l > 1000) { q->l = 0; q->s = 0; q->skip = 1; return; }     /* 1000 = MIRGE_MAX_READ_LEN: the library refuses longer reads */
     if (l <= P->seedmm) { q->l = l; q->s = 0; q->skip = 1; return; }  /* "length <= # seed mismatches" => skipped */
     q->l = l;
     q->s = P->seedlen < l ? P->seedlen : l;
     for (int i = 0; i < l; ++i) {
         char c = read[P->trim5 + i];
-        q->r[1][i] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'N';
+        if (c >= 'a' && c <= 'z') c = (char)(c - 32);          /* hypothesis H4: bowtie's read parser takes a/c/g/t as the base ... */
+        q->r[1][i] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'N';   /* ... and any other character ('.', IUPAC codes) as N */
     }
     for (int i = 0; i < l; ++i) q->r[0][i] = comp_of(q->r[1][l - 1 - i]);
 }

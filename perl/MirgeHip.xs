@@ -125,7 +125,7 @@ mirge_counts(ctx, n_samples)
     PREINIT:
         const uint64_t *q, *is, *cat, *lh, *tu; AV *aq, *ai, *ac, *al, *at; int M, i;
     PPCODE:
-        /* returns five array refs: quant[M*S], iscan[M*S], category[5*S], len_hist[125*S], trimmed_uniq[S] */
+        /* returns five array refs: quant[M*S], iscan[M*S], category[5*S], len_hist[(MIRGE_MAX_READ_LEN+1)*S], trimmed_uniq[S] */
         if (mirge_counts(ctx, &q, &is, &cat, &lh, &tu) != MIRGE_OK) croak("MirgeHip::counts: %s", mirge_last_error(ctx));
         M = mirge_lib_size(ctx, MIRGE_LIB_MIRNA);
         aq = newAV(); ai = newAV(); ac = newAV(); al = newAV(); at = newAV();
@@ -141,21 +141,22 @@ void
 mirge_export_bulk(ctx)
         MirgeHip ctx
     PREINIT:
-        uint64_t U, nnz; SV *seqs, *lens, *rnd, *ref, *amb, *uid, *smp, *cnt; const uint32_t stride = 128;
+        uint64_t U, nnz; SV *seqs, *lens, *rnd, *ref, *amb, *uid, *smp, *cnt; uint32_t stride;
     PPCODE:
         /* the whole per-unique result in ONE call, as packed strings for unpack():
-           (U, stride, seqs[U*stride] zero padded, lens "C*", ann_round "c*", ann_ref "l*", ann_amb "C*",
+           (U, stride, seqs[U*stride] zero padded, lens "S*", ann_round "c*", ann_ref "l*", ann_amb "C*",
             nnz, unique id "Q*", sample "L*", count "L*")  -- the sparse unique x sample counts are triplets */
         U = mirge_n_unique(ctx); nnz = mirge_n_counts(ctx);
-        seqs = newSV(U * stride + 1); lens = newSV(U + 1); rnd = newSV(U + 1); ref = newSV(U * 4 + 1); amb = newSV(U + 1);
+        stride = mirge_max_unique_len(ctx); if (stride < 1) stride = 1;
+        seqs = newSV(U * stride + 1); lens = newSV(U * 2 + 1); rnd = newSV(U + 1); ref = newSV(U * 4 + 1); amb = newSV(U + 1);
         uid = newSV(nnz * 8 + 1); smp = newSV(nnz * 4 + 1); cnt = newSV(nnz * 4 + 1);
         SvPOK_only(seqs); SvPOK_only(lens); SvPOK_only(rnd); SvPOK_only(ref); SvPOK_only(amb); SvPOK_only(uid); SvPOK_only(smp); SvPOK_only(cnt);
-        if (mirge_export_uniques(ctx, SvPVX(seqs), stride, (uint8_t*)SvPVX(lens), (int8_t*)SvPVX(rnd), (int32_t*)SvPVX(ref), (uint8_t*)SvPVX(amb)) != MIRGE_OK ||
+        if (mirge_export_uniques(ctx, SvPVX(seqs), stride, (uint16_t*)SvPVX(lens), (int8_t*)SvPVX(rnd), (int32_t*)SvPVX(ref), (uint8_t*)SvPVX(amb)) != MIRGE_OK ||
             mirge_export_counts(ctx, (uint64_t*)SvPVX(uid), (uint32_t*)SvPVX(smp), (uint32_t*)SvPVX(cnt)) != MIRGE_OK) {
             SvREFCNT_dec(seqs); SvREFCNT_dec(lens); SvREFCNT_dec(rnd); SvREFCNT_dec(ref); SvREFCNT_dec(amb); SvREFCNT_dec(uid); SvREFCNT_dec(smp); SvREFCNT_dec(cnt);
             croak("MirgeHip::export_bulk: %s", mirge_last_error(ctx));
         }
-        SvCUR_set(seqs, U * stride); SvCUR_set(lens, U); SvCUR_set(rnd, U); SvCUR_set(ref, U * 4); SvCUR_set(amb, U);
+        SvCUR_set(seqs, U * stride); SvCUR_set(lens, U * 2); SvCUR_set(rnd, U); SvCUR_set(ref, U * 4); SvCUR_set(amb, U);
         SvCUR_set(uid, nnz * 8); SvCUR_set(smp, nnz * 4); SvCUR_set(cnt, nnz * 4);
         EXTEND(SP, 11);
         mPUSHu((UV)U); mPUSHu((UV)stride); mPUSHs(seqs); mPUSHs(lens); mPUSHs(rnd); mPUSHs(ref); mPUSHs(amb);

@@ -58,7 +58,7 @@ if (!defined $out) {
     print "nUnique\t$U\n";
     # the bulk export must say what the per-unique accessor says
     my ($bU, $stride, $bseqs, $blens, $brnd, $bref, $bamb, $nnz, $buid, $bsmp, $bcnt) = MirgeHip::export_bulk($ctx);
-    my @lens = unpack("C*", $blens); my @rnd = unpack("c*", $brnd); my @ref = unpack("l*", $bref); my @amb = unpack("C*", $bamb);
+    my @lens = unpack("S*", $blens); my @rnd = unpack("c*", $brnd); my @ref = unpack("l*", $bref); my @amb = unpack("C*", $bamb);
     my @uid = unpack("Q*", $buid); my @smp = unpack("L*", $bsmp); my @cnt = unpack("L*", $bcnt);
     my @percount; $percount[$uid[$_]][$smp[$_]] += $cnt[$_] for (0 .. $nnz - 1);
     die "bulk export: unique count differs\n" unless $bU == $U;
@@ -111,7 +111,7 @@ stage('summarize_merge_filter');
 
 my ($U, $stride, $bseqs, $blens, $brnd, $bref, $bamb, $nnz, $buid, $bsmp, $bcnt) = MirgeHip::export_bulk($ctx);   # ONE call for all uniques
 stage('export_bulk');
-my @lens = unpack("C*", $blens); my @rnd = unpack("c*", $brnd); my @ref = unpack("l*", $bref);
+my @lens = unpack("S*", $blens); my @rnd = unpack("c*", $brnd); my @ref = unpack("l*", $bref);
 my @uid = unpack("Q*", $buid); my @smp = unpack("L*", $bsmp); my @cnt = unpack("L*", $bcnt);
 my @row = map { [ (0) x $S ] } (1 .. $U);
 $row[$uid[$_]][$smp[$_]] += $cnt[$_] for (0 .. $nnz - 1);

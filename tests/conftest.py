@@ -36,6 +36,7 @@ def hostsim():
     L.sim_lib_free.argtypes = [C.c_void_p]
     L.sim_pack.argtypes = [C.c_char_p, C.c_int32, C.c_void_p]
     L.sim_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sim_match_long.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.sim_fastq.restype = C.c_int64
     L.sim_fastq.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     L.sim_trim_fastq.restype = C.c_int64

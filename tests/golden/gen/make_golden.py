@@ -226,10 +226,29 @@ def case_long(name="synth_long", seed=synth.BASE_SEED + 21):
     run_reference(d, name, fq)
 
 
+def case_verbatim(name="synth_verbatim", seed=synth.BASE_SEED + 31):
+    """Reads no 2-bit key holds (miRge.pl:306 keys the hash by whatever line 2 holds): 125 .. 400 nt, lower and mixed case,
+    IUPAC codes, '.', 'x', '-', '*' -- among ordinary reads, some in both samples.  orc-bowtie reads a/c/g/t as the base and
+    every other character as N (hypothesis H4)."""
+    from tests import util
+    d = os.path.join(GOLD, name)
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    libs, merges = synth.make_libraries(synth.Profile.tiny(), seed)
+    synth.write_species_dir(os.path.join(d, "species"), libs, merges, with_dummy_ebwt=False)
+    fq = []
+    for s in range(2):
+        seqs, lens = synth.make_reads(libs, 1000, seed + 100 + s)
+        reads = util.with_verbatim(libs, seqs, lens, seed=seed + (0 if s == 0 else 0), n=80)   # the same odd reads in both samples
+        write_fastq(os.path.join(d, "s%d.fastq" % s), reads)
+        fq.append("s%d.fastq" % s)
+    run_reference(d, name, fq)
+
+
 CASES = {"toy": case_toy,
          "synth_tiny": lambda: case_synth("synth_tiny", synth.Profile.tiny(), 1500, 3, synth.BASE_SEED + 7),
          "synth_isomir": lambda: case_synth("synth_isomir", synth.Profile.tiny(), 1200, 2, synth.BASE_SEED + 11, synth.Mixture.isomir_rich()),
-         "synth_long": case_long}
+         "synth_long": case_long, "synth_verbatim": case_verbatim}
 
 if __name__ == "__main__":
     if not os.path.exists(REF):

@@ -123,8 +123,25 @@ int32_t sim_match(void* lib, const uint64_t* key, int32_t kw, const int32_t* rou
     return ok ? 1 : 0;
 }
 
+// a read no key holds, through match_long (kernels.h): 1 = aligned (ref, amb filled), 0 = not
+int32_t sim_match_long(void* lib, const char* seq, int32_t len, const int32_t* round8, int32_t* ref, int32_t* amb) {
+    SimLib* S = (SimLib*)lib;
+    RoundDev P{round8[0], round8[1], round8[2], round8[3], round8[4], round8[5], round8[6], round8[7]};
+    std::vector<uint64_t> rec((size_t)verb_words(len));
+    verb_pack(seq, len, rec.data());
+    const LibDev L = S->dev();
+    uint64_t score, kmax, kmin;
+    match_long(rec.data(), len, L, P, score, kmax, kmin);
+    *ref = -1; *amb = 0;
+    if (!score) return 0;
+    *ref = (int32_t)ref_of(L, (uint32_t)(score >> 1));
+    *amb = ref_of(L, (uint32_t)kmax) != ref_of(L, 0xFFFFFFFFu - (uint32_t)kmin);
+    return 1;
+}
+
 // FASTQ text -> keys, lane by lane as k_fq_count / k_fq_index / k_fq_pack do it.  data must be 16-byte aligned and
-// readable up to the next multiple of 16.  keys: 6 words per record; kw[i] = 2 or 6.  Returns the record count, or
+// readable up to the next multiple of 16.  keys: 6 words per record; kw[i] = 2 or 6, or 0 for a verbatim read (then
+// keys[6i] = offset of its first byte, keys[6i+1] = its length).  Returns the record count, or
 // -4 / -5 (the pack pass's error codes).  win = bytes per window (the product uses 2^31; tests pass small values).
 int64_t sim_fastq(const uint8_t* data, uint64_t size, uint64_t win, uint64_t* keys, int32_t* kw, uint64_t cap) {
     uint64_t newlines = 0;
@@ -155,8 +172,13 @@ int64_t sim_fastq(const uint8_t* data, uint64_t size, uint64_t win, uint64_t* ke
     for (uint64_t i = 0; i < n; ++i) {
         uint64_t sq[4], nm[2]; int len; bool hasN;
         int rc = fq_pack_read(data, size, start[i] == FQ_NONE ? size : start[i], sq, nm, len, hasN);
-        if (rc) return -rc;
         uint64_t* k = keys + 6 * i;
+        if (rc) {
+            rc = fq_line_scan<false>(data, size, start[i], len);
+            if (rc) return -rc;
+            k[0] = start[i]; k[1] = (uint64_t)len; kw[i] = 0;
+            continue;
+        }
         if (!hasN && len <= 56) { k[0] = sq[0]; k[1] = sq[1] | ((uint64_t)len << 56); kw[i] = 2; }
         else { k[0] = sq[0]; k[1] = sq[1]; k[2] = sq[2]; k[3] = sq[3] | ((uint64_t)len << 56); k[4] = nm[0]; k[5] = nm[1]; kw[i] = 6; }
     }
@@ -164,7 +186,7 @@ int64_t sim_fastq(const uint8_t* data, uint64_t size, uint64_t win, uint64_t* ke
 }
 
 // Raw FASTQ text through the device code of trim.h, record by record (index pass as sim_fastq, then trim_record).
-// keys: 6 words per KEPT record, kw = 2 / 6; out[0] = records, out[1] = kept, out[2] = phred base used, out[3] = phred
+// keys: 6 words per KEPT record, kw = 2 / 6, or 0 for a verbatim read (k[0] = offset of its first byte, k[1] = length); out[0] = records, out[1] = kept, out[2] = phred base used, out[3] = phred
 // reported.  Returns kept, or -4 / -5 / -6 (the kernel's error codes), -1 bad spec / cap.
 int64_t sim_trim_fastq(const uint8_t* data, uint64_t size, const char* adapter, int32_t trim5, int32_t trim3,
                        uint64_t* keys, int32_t* kw, uint64_t cap, int64_t* out) {
@@ -192,13 +214,14 @@ int64_t sim_trim_fastq(const uint8_t* data, uint64_t size, const char* adapter, 
     uint64_t kept = 0;
     uint32_t col[TRIM_MAX_ALEN + 1];
     for (uint64_t i = 0; i < n; ++i) {
-        uint64_t ks[4], kn[2]; int len = 0;
+        uint64_t ks[4], kn[2]; int len = 0, oa = 0, ob = 0;
         int rc = trim_record(data, size, st[i] == FQ_NONE ? size : st[i], qs[i] == FQ_NONE ? size : qs[i], qe[i] == FQ_NONE ? size : qe[i],
-                             T, col, 1, ks, kn, len);
-        if (rc > 1) return -rc;
+                             T, col, 1, ks, kn, len, oa, ob);
+        if (rc > 2) return -rc;
         if (rc == 0) continue;
         if (kept >= cap) return -1;
         uint64_t* k = keys + 6 * kept;
+        if (rc == 2) { k[0] = st[i] + (uint64_t)oa; k[1] = (uint64_t)(ob - oa); kw[kept] = 0; ++kept; continue; }
         if (!(kn[0] | kn[1]) && len <= 56) { k[0] = ks[0]; k[1] = ks[1] | ((uint64_t)len << 56); kw[kept] = 2; }
         else { k[0] = ks[0]; k[1] = ks[1]; k[2] = ks[2]; k[3] = ks[3] | ((uint64_t)len << 56); k[4] = kn[0]; k[5] = kn[1]; kw[kept] = 6; }
         ++kept;

@@ -36,7 +36,8 @@ def sim_parse(hostsim, data: bytes, win=1 << 31):
     n = hostsim.sim_fastq(pad.ctypes.data, size, win, keys.ctypes.data, kw.ctypes.data, cap)
     if n < 0:
         return n
-    return [decode(keys[i], int(kw[i])) for i in range(n)]
+    # kw 0: a verbatim read (no key holds it) -- the pass reports where its bytes lie
+    return [decode(keys[i], int(kw[i])) if kw[i] else data[int(keys[i][0]):int(keys[i][0]) + int(keys[i][1])] for i in range(n)]
 
 
 def random_fastq(rng, n, maxlen=60, with_n=True, tricky_quals=True):
@@ -82,11 +83,17 @@ def test_edge_files(hostsim):
     assert sim_parse(hostsim, b"\n\n\n\n\n") == [b"", b""]
     assert sim_parse(hostsim, b"@h\nAC\n+\nII\n@g\n\n+\n\n") == [b"AC", b""]
     assert sim_parse(hostsim, b"@a\n" + b"A" * 124 + b"\n+\n\n") == [b"A" * 124]
-    assert sim_parse(hostsim, b"@a\n" + b"A" * 125 + b"\n+\n\n") == -5
-    assert sim_parse(hostsim, b"@a\n" + b"A" * 300 + b"\n+\n\n") == -5
-    assert sim_parse(hostsim, b"@a\nACGT\r\n+\nIIII\r\n") == -4          # chomp keeps "\r": not a nucleotide
-    assert sim_parse(hostsim, b"@a\nacgt\n+\nIIII\n") == -4
+    # reads no key holds are verbatim reads (miRge.pl:306 keys the hash by whatever the line holds)
+    assert sim_parse(hostsim, b"@a\n" + b"A" * 125 + b"\n+\n\n") == [b"A" * 125]
+    assert sim_parse(hostsim, b"@a\n" + b"A" * 300 + b"\n+\n\n") == [b"A" * 300]
+    assert sim_parse(hostsim, b"@a\n" + b"ACGT" * 250) == [b"ACGT" * 250]
+    assert sim_parse(hostsim, b"@a\n" + b"A" * 1001 + b"\n+\n\n") == -5
+    assert sim_parse(hostsim, b"@a\nacgt\n+\nIIII\n") == [b"acgt"]
+    assert sim_parse(hostsim, b"@a\nAC.RT\n+\nIIIII\n@b\nACGT\n+\nIIII\n") == [b"AC.RT", b"ACGT"]
+    assert sim_parse(hostsim, b"@a\nACGT\r\n+\nIIII\r\n") == -4          # chomp keeps "\r": refused (control character)
     assert sim_parse(hostsim, b"@a\nAC GT\n+\nIIII\n") == -4
+    assert sim_parse(hostsim, b"@a\nAC\tGT\n+\nIIII\n") == -4
+    assert sim_parse(hostsim, b"@a\nAC\xc3GT\n+\nIIII\n") == -4
     # 57 nt / N -> wide key; 56 nt ACGT -> narrow key: both decode to the same text
     assert sim_parse(hostsim, b"@a\n" + b"ACGT" * 14 + b"\n+\n\n@b\n" + b"ACGT" * 14 + b"A\n+\n\n@c\nNACGN\n+\n\n") == \
         [b"ACGT" * 14, b"ACGT" * 14 + b"A", b"NACGN"]

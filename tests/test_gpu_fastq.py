@@ -75,8 +75,8 @@ def test_every_truncation_point(ctx):
 
 
 def test_errors(ctx, tmp_path):
-    for data, code in [(b"@a\n" + b"A" * 125 + b"\n+\n\n", capi.MIRGE_E_LIMIT), (b"@a\n" + b"A" * 300 + b"\n+\n\n", capi.MIRGE_E_LIMIT),
-                       (b"@a\nACGT\r\n+\nIIII\r\n", capi.MIRGE_E_FORMAT), (b"@a\nacgt\n+\nIIII\n", capi.MIRGE_E_FORMAT)]:
+    for data, code in [(b"@a\n" + b"A" * 1001 + b"\n+\n\n", capi.MIRGE_E_LIMIT), (b"@a\n" + b"A" * 3000 + b"\n+\n\n", capi.MIRGE_E_LIMIT),
+                       (b"@a\nACGT\r\n+\nIIII\r\n", capi.MIRGE_E_FORMAT), (b"@a\nac gt\n+\nIIIII\n", capi.MIRGE_E_FORMAT)]:
         ctx.reset()
         with pytest.raises(capi.MirgeError) as e:
             ctx.collapse_fastq_mem(data, 0)

@@ -115,10 +115,10 @@ def test_errors_fail_loudly():
     with capi.Context(None, 1, 0) as ctx:
         util.load_libs_into(ctx, libs)
         with pytest.raises(capi.MirgeError) as e:
-            ctx.collapse_seqs(["ACGT", "ACGU"], 0)
+            ctx.collapse_seqs(["ACGT", "AC GU"], 0)
         assert e.value.code == -4
         with pytest.raises(capi.MirgeError) as e:
-            ctx.collapse_seqs(["A" * 125], 0)
+            ctx.collapse_seqs(["A" * (capi.MAX_READ_LEN + 1)], 0)
         assert e.value.code == -5
         with pytest.raises(capi.MirgeError):
             ctx.collapse_seqs(["ACGT"], 3)

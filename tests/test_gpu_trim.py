@@ -56,8 +56,8 @@ def test_raw_equals_trimmed_path(ctx):
 
 def test_errors(ctx):
     for data, code in [(b"@r\nACGTACGTACGTACGTACGT\n+\nIIII\n", capi.MIRGE_E_FORMAT),
-                       (b"@r\n" + b"A" * 125 + b"\n+\n" + b"I" * 125 + b"\n", capi.MIRGE_E_LIMIT),
-                       (b"@r\nACGTACGTACGTACGTAXGT\n+\n" + b"I" * 20 + b"\n", capi.MIRGE_E_FORMAT)]:
+                       (b"@r\n" + b"A" * 1001 + b"\n+\n" + b"I" * 1001 + b"\n", capi.MIRGE_E_LIMIT),
+                       (b"@r\nACGTACGTACGTACGTA GT\n+\n" + b"I" * 20 + b"\n", capi.MIRGE_E_FORMAT)]:
         ctx.reset()
         with pytest.raises(capi.MirgeError) as e:
             ctx.collapse_raw_fastq_mem(data, 0, "none")

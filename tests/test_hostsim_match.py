@@ -103,6 +103,39 @@ def test_match_one_equals_brute_force(hostsim, oracle, seed, kb, with_n, lo, hi,
     assert n_aligned > 100
 
 
+@pytest.mark.parametrize("seed,kb,lo,hi", [(21, 5, 1, 60), (22, 8, 100, 400), (23, 10, 125, 300), (24, 4, 20, 130), (25, 12, 57, 260)])
+def test_match_long_equals_brute_force(hostsim, oracle, seed, kb, lo, hi):
+    """match_long (kernels.h: the matcher of the verbatim uniques -- reads longer than 124 nt, lower case, IUPAC codes,
+    '.') against the oracle's exhaustive matcher, and against match_one wherever a key holds the read too."""
+    rng = np.random.default_rng(seed)
+    seqs = _make_lib(rng, 16, 60, 700, with_n=True)
+    sim = Sim(hostsim, seqs, kb, 0)
+    olib = OracleLib(seqs)
+    reads = _reads_from(rng, seqs, 160, lo, hi, with_n=True)
+    for i in range(0, len(reads), 3):                 # characters only the verbatim class takes
+        r = reads[i]
+        u = rng.random()
+        if u < 0.4:
+            reads[i] = r.lower()
+        elif u < 0.8:
+            p = int(rng.integers(0, len(r))); reads[i] = r[:p] + str(rng.choice(list("RYKMSWBDHV.x"))) + r[p + 1:]
+        else:
+            reads[i] = "".join(c.lower() if rng.random() < 0.5 else c for c in r)
+    extra_rounds = [(0, 0, 0, 2, 1, 10, 3, 3), (0, 0, 0, 0, 3, 28, 2, 0), (0, 0, 0, 0, 0, 12, 0, 3), (0, 0, 0, 1, 2, 28, 1, 2), (0, 0, 0, 0, 0, 40, 2, 3)]
+    n_aligned = 0
+    for rd in reads:
+        for rnd in list(MIRGE_ROUNDS) + extra_rounds:
+            h = olib.match(rd, rnd)
+            r = np.array(rnd, dtype=np.int32); ref = C.c_int32(); amb = C.c_int32()
+            hostsim.sim_match_long(sim.h, rd.encode(), len(rd), r.ctypes.data, C.byref(ref), C.byref(amb))
+            assert ref.value == h.ref, (rd, rnd, ref.value, h.ref, h.off, h.fw, h.mm, h.stratum)
+            assert amb.value == h.ambiguous, (rd, rnd)
+            if len(rd) <= 124 and all(c in "ACGTN" for c in rd):
+                assert sim.match(rd, rnd)[1:] == (ref.value, amb.value)
+            n_aligned += h.ref >= 0
+    assert n_aligned > 60
+
+
 def test_oracle_indexed_equals_brute(oracle):
     rng = np.random.default_rng(11)
     seqs = _make_lib(rng, 40, 20, 200, with_n=True)

@@ -66,17 +66,33 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 libs, _ = synth.make_libraries(synth.Profile.tiny(), 57)
 S = 2
-samples = [synth.make_reads(libs, 4000, 58 + s) for s in range(S)]
-all_reads = sorted({r for sq, ln in samples for r in synth.reads_to_list(sq, ln)})
+samples = [util.with_verbatim(libs, *synth.make_reads(libs, 4000, 58 + s), seed=s) for s in range(S)]
+all_reads = sorted({r for rd in samples for r in rd if util.fits_key(r)})
 ident = {r: i for i, r in enumerate(all_reads)}          # the double's 16-byte key: (sequence id, 0)
 
 class TableDouble:
     """capi.Context's exchange surface on host memory: lets shard.merge_uniques run under gloo without a GPU."""
     def __init__(self):
         self.tab = {}
+        self.verb = {}                                       # reads no key holds: (string, sample) -> count
     def add(self, reads, sample):
         for r in reads:
-            self.tab[(ident[r], sample)] = self.tab.get((ident[r], sample), 0) + 1
+            if util.fits_key(r):
+                self.tab[(ident[r], sample)] = self.tab.get((ident[r], sample), 0) + 1
+            else:
+                self.verb[(r, sample)] = self.verb.get((r, sample), 0) + 1
+    def verb_export(self):
+        out = b"".join(np.array([len(r), s, c], dtype=np.uint32).tobytes() + r.encode() for (r, s), c in sorted(self.verb.items()))
+        return np.frombuffer(out, dtype=np.uint8)
+    def verb_clear(self):
+        self.verb = {}
+    def verb_import(self, blob, rank, w):
+        b = bytes(blob); p = 0
+        while p < len(b):
+            n, s, c = np.frombuffer(b[p:p + 12], dtype=np.uint32); p += 12
+            r = b[p:p + int(n)].decode(); p += int(n)
+            if zlib.crc32(r.encode()) % w == rank:
+                self.verb[(r, int(s))] = self.verb.get((r, int(s)), 0) + int(c)
     def _owner(self, sid, w):
         return zlib.crc32(all_reads[sid].encode()) % w
     def shard_export_sizes(self, w):
@@ -98,13 +114,16 @@ class TableDouble:
             self.tab[k] = self.tab.get(k, 0) + (int(tail) >> 32)
 
 t = TableDouble()
-for s, (sq, ln) in enumerate(samples):
-    lo, hi = shard.shard_bounds(len(ln), rank, world)
-    t.add(synth.reads_to_list(sq[lo:hi], ln[lo:hi]), s)
+for s, rd in enumerate(samples):
+    lo, hi = shard.shard_bounds(len(rd), rank, world)
+    t.add(rd[lo:hi], s)
 shard.merge_uniques(t, dist, None)
+held = torch.tensor([len(t.verb)]); dist.all_reduce(held)
+assert int(held) == len({(r, s) for s, rd in enumerate(samples) for r in rd if not util.fits_key(r)})     # every verbatim entry on exactly one rank
 owned = {sid for sid, _ in t.tab}
-per_sample = [[all_reads[sid] for (sid, s), c in sorted(t.tab.items()) if s == smp for _ in range(c)] for smp in range(S)]
-res = orc.run_path(util.oracle_libs(libs, orc), per_sample, use_index=True, maxlen=124)
+per_sample = [[all_reads[sid] for (sid, s), c in sorted(t.tab.items()) if s == smp for _ in range(c)] +
+              [r for (r, s), c in sorted(t.verb.items()) if s == smp for _ in range(c)] for smp in range(S)]
+res = orc.run_path(util.oracle_libs(libs, orc), per_sample, use_index=True, maxlen=1000)
 flat = np.concatenate([res[k].ravel() for k in ("quant", "iscan", "cat", "lenhist", "tuniq", "stats")]).astype(np.uint64)
 tot = shard.allreduce_flat(flat, dist)
 own = torch.zeros(len(all_reads), dtype=torch.int64); own[sorted(owned)] = 1
@@ -128,7 +147,7 @@ def test_two_rank_unique_merge_makes_everything_additive(tmp_path, oracle):
                            "--master-addr", "127.0.0.1", "--master-port", "29534", str(w)], env=env, timeout=300)
     tot = np.load(out)
     libs, _ = synth.make_libraries(synth.Profile.tiny(), 57)
-    samples = [synth.make_reads(libs, 4000, 58 + s) for s in range(2)]
-    res = oracle.run_path(util.oracle_libs(libs, oracle), samples, use_index=True, maxlen=124)
+    samples = [util.with_verbatim(libs, *synth.make_reads(libs, 4000, 58 + s), seed=s) for s in range(2)]
+    res = oracle.run_path(util.oracle_libs(libs, oracle), samples, use_index=True, maxlen=1000)
     one = np.concatenate([res[k].ravel() for k in ("quant", "iscan", "cat", "lenhist", "tuniq", "stats")]).astype(np.uint64)
     assert np.array_equal(tot, one)

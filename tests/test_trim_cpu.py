@@ -20,7 +20,8 @@ def sim_trim(hostsim, data: bytes, adapter: str, trim5=0, trim3=0):
     n = hostsim.sim_trim_fastq(pad.ctypes.data, size, adapter.encode(), trim5, trim3, keys.ctypes.data, kw.ctypes.data, cap, out.ctypes.data)
     if n < 0:
         return n
-    return [decode(keys[i], int(kw[i])) for i in range(n)], int(out[0]), int(out[2]), int(out[3])
+    rd = [decode(keys[i], int(kw[i])) if kw[i] else data[int(keys[i][0]):int(keys[i][0]) + int(keys[i][1])] for i in range(n)]
+    return rd, int(out[0]), int(out[2]), int(out[3])
 
 
 def raw_case(seed, n=1500, **kw):
@@ -78,9 +79,28 @@ def test_phred_is_decided_on_the_first_record(hostsim):
 
 def test_errors(hostsim):
     assert sim_trim(hostsim, b"@r\nACGTACGTACGTACGTACGT\n+\nIIII\n", "none") == -6        # quality line shorter than the sequence
-    assert sim_trim(hostsim, b"@r\n" + b"A" * 125 + b"\n+\n" + b"I" * 125 + b"\n", "none") == -5
-    assert sim_trim(hostsim, b"@r\nACGTACGTACGTACGTAXGT\n+\n" + b"I" * 20 + b"\n", "none") == -4
+    assert sim_trim(hostsim, b"@r\n" + b"A" * 1001 + b"\n+\n" + b"I" * 1001 + b"\n", "none") == -5
+    assert sim_trim(hostsim, b"@r\nACGTACGTACGTACGTA GT\n+\n" + b"I" * 20 + b"\n", "none") == -4
+    # lines no key holds are trimmed on their bytes; what is left is a verbatim read unless it fits a key by then
+    assert sim_trim(hostsim, b"@r\n" + b"A" * 125 + b"\n+\n" + b"I" * 125 + b"\n", "none")[0] == [b"A" * 125]
+    assert sim_trim(hostsim, b"@r\nACGTACGTACGTACGTAXGT\n+\n" + b"I" * 20 + b"\n", "none")[0] == [b"ACGTACGTACGTACGTAXGT"]
+    assert sim_trim(hostsim, b"@r\n" + b"ACGT" * 40 + b"\n+\n" + b"I" * 30 + b"#" * 130 + b"\n", "none")[0] == [b"ACGT" * 7 + b"AC"]
     assert sim_trim(hostsim, b"", "none")[0] == []
+
+
+@pytest.mark.parametrize("seed,kw", [(31, {"read_len": 150}), (32, {"read_len": 150, "odd": 0.3}), (33, {"read_len": 75, "odd": 0.5}),
+                                     (34, {"read_len": 250, "odd": 0.1, "adapter_error": 0.5}), (35, {"read_len": 300, "adapter": "A" * 4})])
+def test_lines_no_key_holds(hostsim, seed, kw):
+    """Raw lines beyond 124 nt (150-nt runs with the adapter still on) and reads with lower case / IUPAC codes / '.':
+    trimmed on their bytes, equal to the restatement; most inserts fit a key once the adapter is off, the rest come out
+    as verbatim reads."""
+    data = raw_case(seed, n=1200, **kw)
+    for adapter, t5, t3 in ((A, 0, 0), (A, 1, 2), ("none", 0, 0), ("-7", 0, 1)):
+        want, total, base, reported = otrim.trim_fastq(data, adapter, t5, t3)
+        got = sim_trim(hostsim, data, adapter, t5, t3)
+        assert not isinstance(got, int), got
+        assert (got[0], got[1], got[2], got[3]) == (want, total, base, reported), (adapter, t5, t3)
+        assert len(want) > 100
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])

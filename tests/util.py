@@ -68,7 +68,8 @@ class OracleCtx:
 
     def export_uniques(self):
         U = self.n_unique()
-        seqs = np.zeros((U, 128), dtype=np.uint8); lens = np.zeros(U, dtype=np.uint8)
+        stride = max([128] + [len(s) for s in self.res["uniques"]])
+        seqs = np.zeros((U, stride), dtype=np.uint8); lens = np.zeros(U, dtype=np.uint16)
         for i, s in enumerate(self.res["uniques"]):
             seqs[i, :len(s)] = np.frombuffer(s.encode(), dtype=np.uint8); lens[i] = len(s)
         return seqs, lens, self.res["ann_round"], self.res["ann_ref"], self.res["ann_amb"].astype(np.uint8)
@@ -137,3 +138,56 @@ def gpu_result_dict(ctx):
 def oracle_result_dict(res):
     return {s: (int(res["ann_round"][u]), int(res["ann_ref"][u]), int(res["ann_amb"][u]), tuple(int(x) for x in res["counts"][u]))
             for u, s in enumerate(res["uniques"])}
+
+
+def fits_key(r):
+    """does a device-resident key hold the read (A/C/G/T/N, <= 124 nt)?  Everything else is a verbatim read."""
+    return len(r) <= 124 and all(c in "ACGTN" for c in r)
+
+
+def with_verbatim(libs, seqs, lens, seed=5, n=60):
+    """The sample as list[str] with reads no key holds mixed in (miRge.pl:306 keys them by their exact string, bowtie's
+    parser reads a/c/g/t as the base and anything else as N -- hypothesis H4): lower-case and mixed-case copies of reads
+    of the sample, IUPAC codes and '.', fragments of 125 .. 400 nt of the long libraries with 0-2 substitutions on either
+    strand, and random long reads; several of them more than once and at both ends of the list, so that every
+    contiguous shard of the sample holds some."""
+    from mirge_amd import synth
+    rng = np.random.default_rng(seed)
+    reads = synth.reads_to_list(seqs, lens)
+    odd = []
+    for i in rng.integers(0, len(reads), size=n):
+        r = reads[int(i)]
+        if not r:
+            continue
+        u = rng.random()
+        if u < 0.35:
+            odd.append(r.lower())
+        elif u < 0.5:
+            odd.append("".join(c.lower() if rng.random() < 0.5 else c for c in r))
+        elif u < 0.75:
+            j = int(rng.integers(0, len(r)))
+            odd.append(r[:j] + str(rng.choice(list("RYKMSWBDHV.nx-*"))) + r[j + 1:])
+        else:
+            odd.append(r)
+    comp = str.maketrans("ACGT", "TGCA")
+    for _ in range(n):
+        lib = libs[str(rng.choice(["other", "mrna", "mrna"]))]
+        i = int(rng.integers(0, lib.n))
+        ref = lib.text[int(lib.offs[i]):int(lib.offs[i + 1])].tobytes().decode()
+        if len(ref) < 126 or rng.random() < 0.15:
+            odd.append("".join("ACGT"[x] for x in rng.integers(0, 4, size=int(rng.integers(125, 300)))))
+            continue
+        L = int(rng.integers(125, min(len(ref), 400) + 1))
+        a = int(rng.integers(0, len(ref) - L + 1))
+        r = ref[a:a + L]
+        for _ in range(int(rng.integers(0, 3))):
+            j = int(rng.integers(0, L))
+            r = r[:j] + "ACGT"[("ACGT".index(r[j]) + 1 + int(rng.integers(0, 3))) % 4] + r[j + 1:] if r[j] in "ACGT" else r
+        if rng.random() < 0.4:
+            r = r[::-1].translate(comp)
+        if rng.random() < 0.2:
+            r = r.lower()
+        odd.append(r)
+    odd = [r for r in odd if not fits_key(r)]
+    k = len(odd) // 2
+    return odd[:k] + odd[:k // 2] + reads + odd[k:] + odd[:k // 3]
