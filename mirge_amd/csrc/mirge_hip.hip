@@ -166,7 +166,7 @@ struct Verb {
     }
 };
 
-struct KTime { const char* name; hipEvent_t a = nullptr, b = nullptr; bool used = false; double ms = 0; uint64_t bytes = 0; };
+struct KTime { const char* name; hipEvent_t a = nullptr, b = nullptr; bool used = false, ok = false; double ms = 0; uint64_t bytes = 0; };
 
 }  // namespace
 
@@ -228,12 +228,18 @@ int fail(mirge_ctx* c, int code, const std::string& msg) {
 KTime& ktime(mirge_ctx* c, const char* name) {
     for (auto& k : c->kt) if (k.name == name || !strcmp(k.name, name)) return k;
     KTime k; k.name = name;
-    (void)hipEventCreate(&k.a); (void)hipEventCreate(&k.b);
+    if (hipEventCreate(&k.a) != hipSuccess) k.a = nullptr;
+    if (hipEventCreate(&k.b) != hipSuccess) k.b = nullptr;
     c->kt.push_back(k);
     return c->kt.back();
 }
-void kt_begin(mirge_ctx* c, const char* name, hipStream_t st = nullptr) { KTime& k = ktime(c, name); (void)hipEventRecord(k.a, st ? st : c->st); }
-void kt_end(mirge_ctx* c, const char* name, uint64_t bytes, hipStream_t st = nullptr) { KTime& k = ktime(c, name); (void)hipEventRecord(k.b, st ? st : c->st); k.used = true; k.bytes = bytes; k.ms = -1; }
+// a timing mark that could not be recorded leaves the entry unused (no time is reported for it) instead of a stale one
+void kt_begin(mirge_ctx* c, const char* name, hipStream_t st = nullptr) { KTime& k = ktime(c, name); k.ok = k.a && k.b && hipEventRecord(k.a, st ? st : c->st) == hipSuccess; }
+void kt_end(mirge_ctx* c, const char* name, uint64_t bytes, hipStream_t st = nullptr) {
+    KTime& k = ktime(c, name);
+    k.ok = k.ok && hipEventRecord(k.b, st ? st : c->st) == hipSuccess;
+    k.used = k.ok; k.bytes = bytes; k.ms = -1;
+}
 // st2 picks up after everything queued on st so far / st waits for everything queued on st2 so far
 int fork_st2(mirge_ctx* c) {
     if (hipEventRecord(c->ev_fork, c->st) != hipSuccess || hipStreamWaitEvent(c->st2, c->ev_fork, 0) != hipSuccess) return fail(c, MIRGE_E_HIP, "stream fork failed");
@@ -758,7 +764,7 @@ uint64_t fq_window() {                              // MIRGE_FQ_WINDOW: smaller 
 }
 
 // The trimming step of a raw-FASTQ call (trim.h).  adapter: "none", "illumina", "ion" (miRge.pl:80-86), "+N" / "-N",
-// or up to four comma-separated 3' adapter sequences of <= 32 nt.  base is filled in per file (phred detection).
+// or up to 16 comma-separated 3' adapter sequences of <= 64 nt ("name=SEQ", trailing "$" = anchored).  base is filled in per file (phred detection).
 struct TrimPlan { bool on = false; TrimDev dev; uint64_t kept = 0; int phred_workers = 33, phred_reported = 33; };
 int make_trim_plan(mirge_ctx* c, const char* adapter, int trim5, int trim3, TrimPlan& tp) {
     tp.on = true;
@@ -838,7 +844,8 @@ int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t la
         tp->phred_workers = c->h_ctr[5] ? 64 : 33; tp->phred_reported = c->h_ctr[6] ? 64 : 33;
         tp->dev.base = tp->phred_workers;
         kt_begin(c, "fastq_trim");
-        hipLaunchKernelGGL(k_fq_trim_pack, dim3((uint32_t)((n + TRIM_BLOCK - 1) / TRIM_BLOCK)), dim3(TRIM_BLOCK), 0, c->st, d, size,
+        const uint32_t tb = tp->dev.max_alen > 32 ? TRIM_BLOCK / 2 : TRIM_BLOCK;
+        hipLaunchKernelGGL(k_fq_trim_pack, dim3((uint32_t)((n + tb - 1) / tb)), dim3(tb), (size_t)(tp->dev.max_alen + 1) * tb * 4, c->st, d, size,
                            c->fq_start.as<uint64_t>(), d_qs, d_qe, n, tp->dev, c->stage16.as<uint64_t>(), c->stage48.as<uint64_t>(),
                            c->fq_odd.as<uint64_t>(), c->ctr.as<unsigned long long>());
         kt_end(c, "fastq_trim", size);
@@ -1475,7 +1482,7 @@ void mirge_close(mirge_ctx* c) {
     DevBuf* ws[] = {&c->fq_odd, &c->fq_oddtab, &c->fq_oddpool, &c->ctr, &c->stage16, &c->stage48, &c->in_seqs, &c->in_lens, &c->scan_tmp,
                     &c->fq_raw, &c->fq_seg, &c->fq_segb, &c->fq_start, &c->fq_qstart, &c->fq_qend, &c->sh_ctr, &c->sh_w[0], &c->sh_w[1], &c->hist, &c->off_tmp, &c->state};
     for (auto* b : ws) b->release();
-    for (auto& k : c->kt) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
+    for (auto& k : c->kt) { if (k.a) (void)hipEventDestroy(k.a); if (k.b) (void)hipEventDestroy(k.b); }
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (auto& e : c->ev_t) if (e) (void)hipEventDestroy(e);

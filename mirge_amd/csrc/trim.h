@@ -21,14 +21,16 @@
 
 namespace mg {
 
-constexpr int TRIM_MAX_ADAPTERS = 4, TRIM_MAX_ALEN = 32;
+constexpr int TRIM_MAX_ADAPTERS = 16, TRIM_MAX_ALEN = 64;
 
 struct TrimDev {
     int32_t mode;                          // 0 = no adapter step, 1 = 3' adapters, 2 = unconditional cut
     int32_t uncond;                        // mode 2: > 0 removes first bases, < 0 last bases
     int32_t n_ad;
     int32_t alen[TRIM_MAX_ADAPTERS];
-    uint64_t acode[TRIM_MAX_ADAPTERS];     // 2-bit codes, adapter nt i at bits 2i
+    uint32_t anchored;                     // bit ad: the adapter was written "ADAPTER$" (must end at the read's 3' end)
+    int32_t max_alen;
+    uint64_t acode[TRIM_MAX_ADAPTERS][2];  // 2-bit codes, adapter nt i at bits 2i of the 128-bit value
     int32_t base;                          // phred base of the quality trimmer
     int32_t trim5, trim3, min_len, min_overlap;
     int8_t  maxerr[TRIM_MAX_ALEN + 1];     // [len] = largest cost with (double)cost <= len * rate   (host, in double)
@@ -58,16 +60,25 @@ inline int trim_dev_from_spec(const char* adapter, int trim5, int trim3, TrimDev
         size_t e = a.find(',', p); if (e == std::string::npos) e = a.size();
         std::string one = a.substr(p, e - p);
         p = e + 1;
+        // cutadapt's gather_adapters (trim_file.py:17): "name=SEQUENCE"; a trailing "$" anchors a 3' adapter at the read's end.
+        // Adapter.__init__: upper case, U -> T.
+        const size_t eq = one.find('=');
+        if (eq != std::string::npos) one = one.substr(eq + 1);
+        bool anchored = !one.empty() && one.back() == '$';
+        if (anchored) one.pop_back();
         if (one.empty()) continue;
         if (T.n_ad >= TRIM_MAX_ADAPTERS) { msg = "more than " + std::to_string(TRIM_MAX_ADAPTERS) + " adapters"; return -5; }
         if ((int)one.size() > TRIM_MAX_ALEN) { msg = "adapter longer than " + std::to_string(TRIM_MAX_ALEN) + " nt"; return -5; }
-        uint64_t code = 0;
         for (size_t i = 0; i < one.size(); ++i) {
-            int b = base_code((uint8_t)one[i]);
-            if (b < 0 || b > 3) { msg = "adapter '" + one + "': only plain 3' adapters of A, C, G, T are supported"; return -1; }
-            code |= (uint64_t)b << (2 * i);
+            uint8_t ch = (uint8_t)one[i];
+            if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32);
+            if (ch == 'U') ch = 'T';
+            int b = base_code(ch);
+            if (b < 0 || b > 3) { msg = "adapter '" + one + "': 3' adapters of A, C, G, T (plain, or anchored with a trailing $) are supported; IUPAC wildcards, 5' and linked adapters are not"; return -1; }
+            T.acode[T.n_ad][i >> 5] |= (uint64_t)b << (2 * (i & 31));
         }
-        T.alen[T.n_ad] = (int32_t)one.size(); T.acode[T.n_ad] = code; ++T.n_ad;
+        if (anchored) T.anchored |= 1u << T.n_ad;
+        T.alen[T.n_ad] = (int32_t)one.size(); T.max_alen = std::max<int32_t>(T.max_alen, (int32_t)one.size()); ++T.n_ad;
     }
     if (!T.n_ad) T.mode = 0;
     return 0;
@@ -77,7 +88,8 @@ MG_HD int code_at(const uint64_t (&sq)[4], int j) { return (int)((pick<4>(sq, j 
 MG_HD bool isn_at(const uint64_t (&nm)[2], int j) { return ((j < 64 ? nm[0] : nm[1]) >> (j & 63)) & 1; }
 // How the adapter aligner sees a read: a 2-bit code and "matches nothing" per position.  PackedAcc: a read held as key
 // words (<= 124 nt of A C G T N).  ByteAcc: the sequence line where it lies in the file -- lines no key holds (longer,
-// or with other characters: those match no adapter base, as N does; cutadapt compares the bytes).
+// or with other characters: lower case counts as its base, as cutadapt compares the upper-cased read; anything else
+// matches no adapter base, as N does).
 struct PackedAcc {
     const uint64_t (&sq)[4]; const uint64_t (&nm)[2];
     MG_HD int code(int j) const { return code_at(sq, j); }
@@ -85,8 +97,9 @@ struct PackedAcc {
 };
 struct ByteAcc {
     const uint8_t* __restrict__ line;
-    MG_HD int code(int j) const { const int c = base_code(line[j]); return c < 0 || c > 3 ? 0 : c; }
-    MG_HD bool isn(int j) const { const int c = base_code(line[j]); return c < 0 || c > 3; }
+    MG_HD static int up(uint8_t ch) { return base_code((ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch); }      // match_to compares read.sequence.upper()
+    MG_HD int code(int j) const { const int c = up(line[j]); return c < 0 || c > 3 ? 0 : c; }
+    MG_HD bool isn(int j) const { const int c = up(line[j]); return c < 0 || c > 3; }
 };
 
 // DP cell: cost (bits 24-31) | matches (16-23) | origin (0-15)
@@ -97,13 +110,16 @@ MG_HD int c_origin(uint32_t c) { return (int)(c & 0xFFFF); }
 
 // Adapter `ad` against read nts [a, b): true if it matches; rstart (relative to a) and matches out.
 // col: this lane's DP column, cell i at col[i * stride].
+MG_HD int ad_code(const TrimDev& T, int ad, int i) { return (int)((T.acode[ad][i >> 5] >> (2 * (i & 31))) & 3); }
 template <class Acc>
 MG_HD bool adapter_match(const TrimDev& T, int ad, const Acc& rd, int a, int b,
                          uint32_t* col, int stride, int& rstart, int& matches_out) {
     const int m = T.alen[ad], n = b - a;
-    const uint64_t ac = T.acode[ad];
-    // leftmost exact occurrence: rolling 2m-bit window over the read
-    {
+    const bool anch = (T.anchored >> ad) & 1u;
+    // exact occurrence first: the leftmost one (anchored: only as the read's suffix)
+    if (m <= 32 && !anch) {
+        // rolling 2m-bit window over the read
+        const uint64_t ac = T.acode[ad][0];
         const uint64_t full = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1);
         uint64_t h = 0; int nrun = 0;                        // nrun: nts since the last N
         for (int j = 0; j < n; ++j) {
@@ -112,6 +128,12 @@ MG_HD bool adapter_match(const TrimDev& T, int ad, const Acc& rd, int a, int b,
             h = ((h >> 2) | ((uint64_t)c << (2 * (m - 1)))) & full;
             nrun = isn ? 0 : nrun + 1;
             if (j >= m - 1 && nrun >= m && h == ac) { rstart = j - m + 1; matches_out = m; return true; }
+        }
+    } else {
+        for (int p = anch ? (n - m > 0 ? n - m : 0) : 0; p + m <= n; ++p) {
+            int i = 0;
+            while (i < m && !rd.isn(a + p + i) && rd.code(a + p + i) == ad_code(T, ad, i)) ++i;
+            if (i == m) { rstart = p; matches_out = m; return true; }
         }
     }
     const int k = T.maxerr[m];
@@ -127,7 +149,7 @@ MG_HD bool adapter_match(const TrimDev& T, int ad, const Acc& rd, int a, int b,
         col[0] = up;
         for (int i = 1; i <= last; ++i) {
             const uint32_t cur = col[i * stride];
-            const bool eq = !nj && (int)((ac >> (2 * (i - 1))) & 3) == cj;
+            const bool eq = !nj && ad_code(T, ad, i - 1) == cj;
             uint32_t nw;
             if (eq) nw = cell(c_cost(tmp), c_matches(tmp) + 1, c_origin(tmp));
             else {
@@ -141,7 +163,7 @@ MG_HD bool adapter_match(const TrimDev& T, int ad, const Acc& rd, int a, int b,
         }
         while (last >= 0 && c_cost(col[last * stride]) > k) --last;
         if (last < m) ++last;
-        else {
+        else if (!anch) {                                     // an anchored adapter may only end where the read ends
             const uint32_t c = col[m * stride];
             const int cost = c_cost(c), matches = c_matches(c);
             if (m >= T.min_overlap && cost <= T.maxerr[m] && (matches > best_matches || (matches == best_matches && cost < best_cost))) {
@@ -150,7 +172,7 @@ MG_HD bool adapter_match(const TrimDev& T, int ad, const Acc& rd, int a, int b,
             }
         }
     }
-    for (int i = m; i >= 0; --i) {
+    for (int i = m; i >= (anch ? m : 0); --i) {               // ... and must be taken in whole
         const uint32_t c = col[i * stride];
         const int cost = c_cost(c), matches = c_matches(c);
         if (i >= T.min_overlap && cost <= T.maxerr[i] && (matches > best_matches || (matches == best_matches && cost < best_cost))) {
@@ -251,13 +273,13 @@ MG_HD int trim_record(const uint8_t* __restrict__ data, uint64_t size, uint64_t 
 }
 
 #ifdef __HIPCC__
-constexpr int TRIM_BLOCK = 256;
+constexpr int TRIM_BLOCK = 256;            // 128 when an adapter is longer than 32 nt: the DP columns of a block are LDS, (max_alen + 1) words per lane
 // counters: [0] n16, [1] n48, [2] error code, [3] first offending record, [4] records kept, [7] verbatim reads, [8] their bytes
 __global__ void __launch_bounds__(TRIM_BLOCK)
 k_fq_trim_pack(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* __restrict__ start, const uint64_t* __restrict__ qstart,
                const uint64_t* __restrict__ qend, uint64_t n, TrimDev T, uint64_t* __restrict__ k16, uint64_t* __restrict__ k48,
                uint64_t* __restrict__ odd, unsigned long long* counters) {
-    __shared__ uint32_t s_col[(TRIM_MAX_ALEN + 1) * TRIM_BLOCK];
+    extern __shared__ uint32_t s_col[];                        // (T.max_alen + 1) * blockDim.x words
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t s = start[i], qs = qstart[i], qe = qend[i];
@@ -265,7 +287,7 @@ k_fq_trim_pack(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* 
     if (qs == FQ_NONE) qs = size;
     if (qe == FQ_NONE) qe = size;
     uint64_t ks[4], kn[2]; int len = 0, oa = 0, ob = 0;
-    int rc = trim_record(data, size, s, qs, qe, T, s_col + threadIdx.x, TRIM_BLOCK, ks, kn, len, oa, ob);
+    int rc = trim_record(data, size, s, qs, qe, T, s_col + threadIdx.x, (int)blockDim.x, ks, kn, len, oa, ob);
     if (rc > 2) {
         if (atomicCAS(&counters[2], 0ull, (unsigned long long)rc) == 0ull) counters[3] = i;
         return;

@@ -21,7 +21,7 @@ def lib():
             subprocess.check_call(["make", "-C", HERE, "-s"])
         L = C.CDLL(SO)
         L.orc_quality_trim.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        L.orc_adapter_back.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.orc_adapter_back.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p]
         L.orc_trim_record.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_trim_fastq.restype = C.c_int64
@@ -37,10 +37,10 @@ def quality_trim(qual: bytes, base=33, cutoff_front=0, cutoff_back=10):
     return a.value, b.value
 
 
-def adapter_back(adapter: bytes, read: bytes, rate=0.12, min_overlap=3):
-    """(astart, astop, rstart, rstop, matches, errors) or None"""
+def adapter_back(adapter: bytes, read: bytes, rate=0.12, min_overlap=3, anchored=False):
+    """(astart, astop, rstart, rstop, matches, errors) or None; anchored: the adapter was written 'ADAPTER$'"""
     out = np.zeros(6, dtype=np.int32)
-    ok = lib().orc_adapter_back(adapter, len(adapter), read, len(read), rate, min_overlap, out.ctypes.data)
+    ok = lib().orc_adapter_back(adapter, len(adapter), read, len(read), rate, min_overlap, int(anchored), out.ctypes.data)
     return tuple(int(x) for x in out) if ok else None
 
 

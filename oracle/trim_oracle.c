@@ -22,6 +22,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <ctype.h>
+
 #define ORC_TRIM_MAXADAPTER 64
 
 /* cutadapt qualtrim.quality_trim_index(qualities, cutoff_front, cutoff_back, base) */
@@ -46,7 +48,9 @@ typedef struct { int cost, matches, origin; } Entry;
 
 /* cutadapt _align.Aligner.locate for a back adapter (reference = adapter, query = read).
  * out = {astart, astop, rstart, rstop, matches, errors}; returns 1 if an alignment qualifies. */
-static int locate_back(const char* s1, int m, const char* s2, int n, double max_error_rate, int min_overlap, int out[6]) {
+/* anchored (a 3' adapter written "ADAPTER$": where = SUFFIX, flags = START_WITHIN_SEQ2 alone): the alignment must take in
+ * the whole adapter and end at the read's end -- only cell (m, n) is a candidate. */
+static int locate_back(const char* s1, int m, const char* s2, int n, double max_error_rate, int min_overlap, int anchored, int out[6]) {
     Entry column[ORC_TRIM_MAXADAPTER + 1];
     const int k = (int)(max_error_rate * m);
     for (int i = 0; i <= m; ++i) { column[i].matches = 0; column[i].cost = i; column[i].origin = 0; }
@@ -70,7 +74,7 @@ static int locate_back(const char* s1, int m, const char* s2, int n, double max_
         }
         while (last >= 0 && column[last].cost > k) --last;
         if (last < m) ++last;
-        else {
+        else if (!anchored) {
             /* the whole adapter is aligned and ends inside the read */
             int length = m + (column[m].origin < 0 ? column[m].origin : 0);
             int cost = column[m].cost, matches = column[m].matches;
@@ -84,7 +88,7 @@ static int locate_back(const char* s1, int m, const char* s2, int n, double max_
     /* the read may end inside the adapter: last column, every adapter prefix.  (After the early exit above nothing
        here can win: it would need more than m matches.  Rows the band no longer reaches hold a cost > k from the
        column in which they were dropped, so they cannot qualify either.) */
-    for (int i = m; i >= 0; --i) {
+    for (int i = m; i >= (anchored ? m : 0); --i) {
         int length = i + (column[i].origin < 0 ? column[i].origin : 0);
         int cost = column[i].cost, matches = column[i].matches;
         if (length >= min_overlap && (double)cost <= length * max_error_rate &&
@@ -98,12 +102,19 @@ static int locate_back(const char* s1, int m, const char* s2, int n, double max_
     return 1;
 }
 
-/* cutadapt Adapter(where=BACK, max_error_rate, min_overlap=3, indels=True).match_to(read) */
-int orc_adapter_back(const char* adapter, int m, const char* read, int n, double max_error_rate, int min_overlap, int out[6]) {
-    if (m <= 0 || m > ORC_TRIM_MAXADAPTER) return 0;
-    for (int p = 0; p + m <= n; ++p)
-        if (memcmp(read + p, adapter, (size_t)m) == 0) { out[0] = 0; out[1] = m; out[2] = p; out[3] = p + m; out[4] = m; out[5] = 0; return 1; }
-    if (!locate_back(adapter, m, read, n, max_error_rate, min_overlap, out)) return 0;
+/* cutadapt Adapter(where=BACK or SUFFIX, max_error_rate, min_overlap=3, indels=True).match_to(read): the read is
+ * compared upper-cased (read_seq = read.sequence.upper()), the adapter was upper-cased with U -> T when it was made. */
+int orc_adapter_back(const char* adapter, int m, const char* read_in, int n, double max_error_rate, int min_overlap, int anchored, int out[6]) {
+    if (m <= 0 || m > ORC_TRIM_MAXADAPTER || n < 0 || n > 4096) return 0;
+    char read[4097];
+    for (int i = 0; i < n; ++i) read[i] = (char)toupper((unsigned char)read_in[i]);
+    if (anchored) {
+        if (n >= m && memcmp(read + n - m, adapter, (size_t)m) == 0) { out[0] = 0; out[1] = m; out[2] = n - m; out[3] = n; out[4] = m; out[5] = 0; return 1; }
+    } else {
+        for (int p = 0; p + m <= n; ++p)
+            if (memcmp(read + p, adapter, (size_t)m) == 0) { out[0] = 0; out[1] = m; out[2] = p; out[3] = p + m; out[4] = m; out[5] = 0; return 1; }
+    }
+    if (!locate_back(adapter, m, read, n, max_error_rate, min_overlap, anchored, out)) return 0;
     int length = out[1] - out[0];
     if (length < min_overlap || (double)out[5] / length > max_error_rate) return 0;
     return 1;
@@ -124,9 +135,20 @@ int orc_trim_record(const char* seq, const char* qual, int n, const char* adapte
         int best_matches = -1, best_rstart = -1;
         const char* p = adapters;
         while (*p) {
+            /* gather_adapters (trim_file.py:17): "name=SEQ", a trailing "$" anchors the adapter at the read's 3' end;
+               Adapter.__init__: upper case, U -> T */
             const char* e = strchr(p, ','); int m = e ? (int)(e - p) : (int)strlen(p);
+            const char* q = p; int ql = m;
+            const char* eq = memchr(q, '=', (size_t)ql);
+            if (eq) { ql -= (int)(eq + 1 - q); q = eq + 1; }
+            int anchored = ql > 0 && q[ql - 1] == '$';
+            if (anchored) --ql;
+            char ad[ORC_TRIM_MAXADAPTER + 1];
             int out[6];
-            if (m > 0 && orc_adapter_back(p, m, seq + a, b - a, 0.12, 3, out) && out[4] > best_matches) { best_matches = out[4]; best_rstart = out[2]; }
+            if (ql > 0 && ql <= ORC_TRIM_MAXADAPTER) {
+                for (int i = 0; i < ql; ++i) { char c = (char)toupper((unsigned char)q[i]); ad[i] = c == 'U' ? 'T' : c; }
+                if (orc_adapter_back(ad, ql, seq + a, b - a, 0.12, 3, anchored, out) && out[4] > best_matches) { best_matches = out[4]; best_rstart = out[2]; }
+            }
             p += m; if (*p == ',') ++p;
         }
         if (best_rstart >= 0) b = a + best_rstart;

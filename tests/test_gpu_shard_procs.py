@@ -31,11 +31,12 @@ rng = np.random.default_rng(5)
 for seqs, lens in samples:                                  # some reads of the 48-byte key class
     for i in rng.integers(0, len(lens), size=150):
         seqs[i, int(rng.integers(0, lens[i]))] = ord("N")
+samples = [util.with_verbatim(libs, seqs, lens, seed=s, n=120) for s, (seqs, lens) in enumerate(samples)]    # + reads no key holds (a host-side table)
 with capi.Context(None, S, 0) as ctx:
     util.load_libs_into(ctx, libs)
-    for s, (seqs, lens) in enumerate(samples):
-        lo, hi = shard.shard_bounds(len(lens), rank, world)
-        ctx.collapse_seqs(seqs[lo:hi], s, lens[lo:hi])
+    for s, rd in enumerate(samples):
+        lo, hi = shard.shard_bounds(len(rd), rank, world)
+        ctx.collapse_seqs(rd[lo:hi], s)
     shard.merge_uniques(ctx, dist, dev)
     ctx.annotate()
     mine = util.gpu_result_dict(ctx)
@@ -66,10 +67,11 @@ def test_two_processes_one_gpu_merge_and_allreduce(tmp_path):
     for seqs, lens in samples:
         for i in rng.integers(0, len(lens), size=150):
             seqs[i, int(rng.integers(0, lens[i]))] = ord("N")
+    samples = [util.with_verbatim(libs, seqs, lens, seed=s, n=120) for s, (seqs, lens) in enumerate(samples)]
     with capi.Context(None, 2, 0) as one:
         util.load_libs_into(one, libs)
-        for s, (seqs, lens) in enumerate(samples):
-            one.collapse_seqs(seqs, s, lens)
+        for s, rd in enumerate(samples):
+            one.collapse_seqs(rd, s)
         one.annotate()
         want = util.gpu_result_dict(one)
         want_flat = one.counts_flat()
@@ -79,5 +81,6 @@ def test_two_processes_one_gpu_merge_and_allreduce(tmp_path):
         assert not (set(part) & set(got))                   # every sequence lives on exactly one rank
         got.update(part)
     assert got == want
+    assert sum(1 for k in want if not util.fits_key(k)) > 100
     assert np.array_equal(res["flat"], want_flat)           # count vectors, trimmed_uniq and round statistics: all sums now
     assert [tuple(int(x) for x in r) for r in res["stats"]] == [tuple(int(x) for x in r) for r in want_stats]

@@ -29,9 +29,16 @@ def table(ctx):
     (6, "+11", 2, 0, {}), (7, "-5", 0, 0, {}), (8, A, 0, 0, {"phred": 64}), (9, A, 0, 0, {"crlf": True}),
     (10, "TGGAATTCTCGG," + A, 0, 0, {}), (11, A, 0, 0, {"adapter_error": 0.9, "low_tail": 0.6}), (12, A[:12], 3, 3, {"read_len": 36}),
     (13, A, 0, 0, {"read_len": 124}),
+    # lines no key holds: 150-nt runs with the adapter still on, lower case / IUPAC codes in the reads
+    (14, A, 0, 0, {"read_len": 150}), (15, A, 1, 1, {"read_len": 250, "odd": 0.2}), (16, "none", 0, 0, {"read_len": 150, "odd": 0.3}),
+    # adapter syntax of cutadapt's -a beyond a plain short sequence: anchored, named, lower case, many, long
+    (17, A + "$", 0, 0, {}), (18, "small=" + A.lower() + ",ACGTTGCATGCATGCAAGCTTGACGTACGATCGATCGTACGATCGGTTAACC$", 0, 0, {"read_len": 75}),
+    (19, ",".join([A[:20]] + ["ACGTTGCAAGCTTGACCA"[i:] + "GATTACA" for i in range(9)]), 0, 0, {}),
 ])
 def test_gpu_equals_restatement(ctx, tmp_path, seed, adapter, t5, t3, kw):
     data = raw_case(seed, n=20000, **kw)
+    if seed == 18:          # the second, 50-nt adapter is on a share of the reads instead
+        data += raw_case(seed + 100, n=5000, adapter="ACGTTGCATGCATGCAAGCTTGACGTACGATCGATCGTACGATCGGTTAACC", read_len=75).replace(b"@raw", b"@two")
     want, total, base, reported = otrim.trim_fastq(data, {"illumina": A, "ion": "+11"}.get(adapter, adapter), t5, t3)
     expect = dict(collections.Counter(x.decode() for x in want))
     ctx.reset()
@@ -62,7 +69,7 @@ def test_errors(ctx):
         with pytest.raises(capi.MirgeError) as e:
             ctx.collapse_raw_fastq_mem(data, 0, "none")
         assert e.value.code == code
-    for bad in ("ACGU", "A" * 33, "A,C,G,T,AA"):
+    for bad in ("ACGR", "A" * 65, ",".join(["ACGTAC"] * 17)):
         with pytest.raises(capi.MirgeError):
             ctx.collapse_raw_fastq_mem(b"", 0, bad)
     ctx.reset()

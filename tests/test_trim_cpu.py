@@ -103,6 +103,72 @@ def test_lines_no_key_holds(hostsim, seed, kw):
         assert len(want) > 100
 
 
+def _fq(reads):
+    return b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads))
+
+
+def test_adapter_syntax_known_answers(hostsim):
+    """What cutadapt's -a parser takes beyond a plain short sequence (trim_file.py:14-23, 41): adapters over 32 nt, more
+    than four of them, name=SEQUENCE, lower case / U, and 'ADAPTER$' anchored at the read's 3' end.  Expected values by
+    construction; the restatement (oracle/trim_oracle.c) must give the same."""
+    rng = np.random.default_rng(77)
+    rs = lambda n: bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n).tolist())
+    ins = [rs(22), rs(30), rs(18), rs(41)]
+    long_ad, ad64 = rs(40), rs(64)
+    # (1) 40-nt and 64-nt adapters: whole, cut by the read's end, with one error
+    one_err = bytearray(long_ad); one_err[17] = ord("ACGT"["ACGT".index(chr(one_err[17])) ^ 1])
+    reads = [ins[0] + long_ad, ins[1] + long_ad[:25], ins[2] + bytes(one_err) + b"ACGT", ins[3] + ad64, ins[0] + ad64[:50], ins[1]]
+    for spec in (long_ad.decode() + "," + ad64.decode(), "x=" + long_ad.decode().lower().replace("t", "u") + ",y=" + ad64.decode()):
+        got = sim_trim(hostsim, _fq(reads), spec)
+        assert got[0] == [ins[0], ins[1], ins[2], ins[3], ins[0], ins[1]], spec
+        assert got[0] == otrim.trim_fastq(_fq(reads), spec)[0]
+    # (2) six adapters: the read carrying the fifth is cut where it starts
+    ads = [rs(20) for _ in range(6)]
+    reads = [ins[0] + ads[4] + b"AAAA", ins[1] + ads[5][:12], ins[2] + ads[0], ins[3]]
+    spec = ",".join(a.decode() for a in ads)
+    got = sim_trim(hostsim, _fq(reads), spec)
+    assert got[0][:3] == [ins[0], ins[1], ins[2]] and got[0] == otrim.trim_fastq(_fq(reads), spec)[0]      # (the adapter-free read may lose a chance 3-nt overlap)
+    assert sim_trim(hostsim, _fq(reads), ",".join("ACGTACGTAC" for _ in range(17))) == -1          # more than 16: refused
+    assert sim_trim(hostsim, _fq(reads), "A" * 65) == -1 and sim_trim(hostsim, _fq(reads), "ACGTRYACGT") == -1
+    # (3) anchored: removed only when it ends where the read ends
+    ad = rs(24)
+    reads = [ins[0] + ad, ins[1] + ad + b"ACGTAC", ins[2] + ad[:12], ins[3] + ad[:-1], ins[0] + ad[:10] + b"G" + ad[10:]]
+    spec = ad.decode() + "$"
+    got = sim_trim(hostsim, _fq(reads), spec)
+    assert got[0][0] == ins[0]                      # the whole adapter at the end: removed
+    assert got[0][1] == reads[1]                    # followed by more read: an anchored adapter does not match
+    assert got[0][2] == reads[2]                    # only a prefix of it at the end: not the whole adapter
+    assert got[0][3] == ins[3]                      # whole but for its last base (one deletion <= int(0.12 * 24) = 2 errors): removed
+    assert got[0][4] == ins[0]                      # one inserted base inside: removed
+    assert got[0] == otrim.trim_fastq(_fq(reads), spec)[0]
+    plain = sim_trim(hostsim, _fq(reads), ad.decode())
+    assert plain[0][1] == ins[1] and plain[0][2] == ins[2]                 # the same adapter without the anchor takes both
+    assert otrim.adapter_back(ad, ins[0] + ad, anchored=True)[2:4] == (len(ins[0]), len(ins[0]) + 24)
+    assert otrim.adapter_back(ad, ins[1] + ad + b"ACGTAC", anchored=True) is None
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_random_long_anchored_and_many_adapters(hostsim, seed):
+    """Randomised like the next test: 1-8 adapters of 3-64 nt, every third anchored, lower-case reads now and then."""
+    rng = np.random.default_rng(4100 + seed)
+    libs, _ = synth.make_libraries(synth.Profile.tiny(), 77)
+    for _ in range(8):
+        nad = int(rng.integers(1, 9))
+        ads = ["".join("ACGT"[x] for x in rng.integers(0, 4, size=int(rng.integers(3, 65)))) for _ in range(nad)]
+        spec = ",".join(a + ("$" if rng.random() < 0.33 else "") for a in ads)
+        t5, t3 = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        seqs, lens = synth.make_reads(libs, 300, int(rng.integers(0, 1 << 30)))
+        lens = np.minimum(lens, rng.integers(1, 48, size=len(lens))).astype(lens.dtype)
+        use = ads[int(rng.integers(0, nad))]
+        data = synth.make_raw_fastq(seqs, lens, int(rng.integers(0, 1 << 30)), adapter=use,
+                                    read_len=int(rng.choice([36, 50, 75, 100, 150])) if rng.random() < 0.5 else int(rng.integers(20, 60)) + len(use),
+                                    adapter_error=float(rng.random()), low_tail=float(rng.random()) * 0.3, odd=0.1)
+        want, total, base, reported = otrim.trim_fastq(data, spec, t5, t3)
+        got = sim_trim(hostsim, data, spec, t5, t3)
+        assert not isinstance(got, int), (got, spec)
+        assert (got[0], got[1], got[2], got[3]) == (want, total, base, reported), (spec, t5, t3)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_adapters_lengths_and_cuts(hostsim, seed):
     """Randomised: 1-3 adapters of 3-32 nt (homopolymers now and then), raw read lengths 20-124, inserts cut short so the

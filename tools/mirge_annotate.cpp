@@ -50,6 +50,18 @@ int main(int argc, char** argv) {
         if (mirge_round_stats(c, r, &p, &a, &sec)) return die("round statistics");
         printf("%s: readsProcessed %llu readsAligned %llu cpuTime %.6f\n", rn[r - 1], (unsigned long long)p, (unsigned long long)a, sec);
     }
+    {   // how much of the result rides on hypothesis H1 (which of several equally good references bowtie prints last):
+        // uniques / reads whose best stratum held more than one reference (parity with bowtie unpinned)
+        const uint64_t U = mirge_n_unique(c), E = mirge_n_counts(c);
+        std::vector<int8_t> rnd(U ? U : 1); std::vector<uint8_t> amb(U ? U : 1);
+        std::vector<uint64_t> uid(E ? E : 1); std::vector<uint32_t> cnt(E ? E : 1);
+        if (mirge_export_uniques(c, nullptr, 0, nullptr, rnd.data(), nullptr, amb.data()) || mirge_export_counts(c, uid.data(), nullptr, cnt.data())) return die("per-unique results");
+        uint64_t ua = 0, ut = 0, ra = 0, rt = 0;
+        for (uint64_t u = 0; u < U; ++u) if (rnd[u] > 0) { ++ua; ut += amb[u] != 0; }
+        for (uint64_t e = 0; e < E; ++e) if (rnd[uid[e]] > 0) { ra += cnt[e]; rt += amb[uid[e]] ? cnt[e] : 0; }
+        printf("annotated: %llu uniques / %llu reads; best stratum held several references (assignment follows hypothesis H1): %llu uniques (%.2f%%) / %llu reads (%.2f%%)\n",
+               (unsigned long long)ua, (unsigned long long)ra, (unsigned long long)ut, ua ? 100.0 * ut / ua : 0.0, (unsigned long long)rt, ra ? 100.0 * rt / ra : 0.0);
+    }
     std::vector<const char*> np; for (auto& s : N) np.push_back(s.c_str());
     std::vector<uint64_t> tot(F.size()), uq(F.size());
     if (mirge_write_tables(c, (species + "/merges.csv").c_str(), out.c_str(), np.data(), tot.data(), uq.data())) return die("tables");
