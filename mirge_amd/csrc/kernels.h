@@ -1164,6 +1164,8 @@ MG_HD int slot_kind(const PEnt& e, uint32_t& lo, uint32_t& hi) {
 MG_HD PEnt load_pent(const PEnt* __restrict__ a, uint64_t i) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4* q = reinterpret_cast<const u32x4*>(a + i);
+    // (streaming / nontemporal loads here, meant to keep slot lines from pushing the occupancy bitmaps out of the L2, lost:
+    //  round 3 0.73 -> 0.82 ms, round 5 0.61 -> 1.03 ms -- the lines then miss the Infinity Cache as well)
     const u32x4 v0 = q[0], v1 = q[1];
     PEnt e; e.pos = v0.x; e.info = v0.y; e.c[0] = v0.z; e.c[1] = v0.w; e.c[2] = v1.x; e.c[3] = v1.y; e.c[4] = v1.z; e.c[5] = v1.w;
     return e;
@@ -1409,12 +1411,11 @@ __device__ __forceinline__ void finish_on_text(const uint64_t* __restrict__ ukey
 #ifndef MG_PF
 #define MG_PF 2                                  // queue entries a wave has in flight in phase 2 (4 spills registers: slower)
 #endif
+// one block's worth (MB reads, block number bid of the launch's work) of a round
 template <int KW, int RN>
-__global__ void __launch_bounds__(MB, MG_MATCH_WAVES)
-k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref,
-              uint8_t* ann_amb, LibDev L, RoundDev P, int thr, unsigned long long* stats,
-              const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_n,
-              uint32_t* next_list, unsigned long long* next_n) {
+__device__ __forceinline__ void match_block(const uint32_t bid, const uint32_t n, const uint64_t* __restrict__ ukeys, uint8_t* ann_round, int32_t* ann_ref,
+              uint8_t* ann_amb, const LibDev& L, const RoundDev& P, int thr, unsigned long long* stats,
+              const uint32_t* __restrict__ list, uint32_t* next_list, unsigned long long* next_n) {
     // list (nullable) = the uniques no earlier round annotated, as left by the previous round's launch;
     // next_list (nullable) receives this round's survivors.  Dense lists keep the lanes busy in the
     // later rounds, where most of the table is already annotated.
@@ -1425,9 +1426,7 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     __shared__ uint32_t s_u[MB];
     __shared__ uint32_t s_qn, s_next, s_wcnt[MB / 64], s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t n = list ? (uint32_t)*list_n : U;
-    if (blockIdx.x * MB >= n) return;
-    const uint32_t i = blockIdx.x * MB + tid;
+    const uint32_t i = bid * MB + tid;
     const uint32_t u = i < n ? (list ? list[i] : i) : EMPTY;
     s_u[tid] = u;
     bool active = false;
@@ -1557,7 +1556,7 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
 #ifdef MG_PHASE_PROF
     if (tid == 0) {
         const long long t2_ = clock64();
-        uint32_t slot = blockIdx.x & (STAT_SLOTS - 1);
+        uint32_t slot = bid & (STAT_SLOTS - 1);
         atomicAdd(&stats[(size_t)slot * 8 + 1], (unsigned long long)(t1_ - t0_));
         atomicAdd(&stats[(size_t)slot * 8 + 2], (unsigned long long)(t2_ - t1_));
         atomicAdd(&stats[(size_t)slot * 8 + 3], (unsigned long long)qn);
@@ -1584,7 +1583,7 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     // counters are spread over STAT_SLOTS cache lines: one hot word would cost ~12 ns per wave
     unsigned long long am = __ballot(active), hm = __ballot(hit);
     if (lane == 0) {
-        uint32_t slot = (blockIdx.x * 4 + (tid >> 6)) & (STAT_SLOTS - 1);
+        uint32_t slot = (bid * 4 + (tid >> 6)) & (STAT_SLOTS - 1);
         if (am) atomicAdd(&stats[(size_t)slot * 8], (unsigned long long)__popcll(am));
         if (hm) atomicAdd(&stats[(size_t)(STAT_SLOTS + slot) * 8], (unsigned long long)__popcll(hm));
     }
@@ -1602,6 +1601,22 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         }
         __syncthreads();
         if (surv) next_list[s_base + s_wcnt[tid >> 6] + (uint32_t)__popcll(sm_ & ((1ull << lane) - 1))] = u;
+    }
+}
+
+// The kernel: blocks walk the launch's work with a grid stride, so a launch over a list whose length only the device
+// knows (what the probe kernel hands on: usually a handful of reads) can be a small grid instead of one block per
+// MB uniques of the table that leave at once.
+template <int KW, int RN>
+__global__ void __launch_bounds__(MB, MG_MATCH_WAVES)
+k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref,
+              uint8_t* ann_amb, LibDev L, RoundDev P, int thr, unsigned long long* stats,
+              const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_n,
+              uint32_t* next_list, unsigned long long* next_n) {
+    const uint32_t n = list ? (uint32_t)*list_n : U;
+    for (uint32_t bid = blockIdx.x; (uint64_t)bid * MB < n; bid += gridDim.x) {
+        match_block<KW, RN>(bid, n, ukeys, ann_round, ann_ref, ann_amb, L, P, thr, stats, list, next_list, next_n);
+        __syncthreads();                                   // the block's LDS state is reused by its next piece of work
     }
 }
 

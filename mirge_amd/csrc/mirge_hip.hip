@@ -1124,7 +1124,8 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
                            C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), C.ann_amb.as<uint8_t>(),
                            L, P, RS, c->d_stats + (size_t)r * STAT_WORDS, list, C.act_n + r, next_list, C.act_n + r + 1,
                            C.fb.as<uint32_t>(), C.fb_n + r);
-        hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((C.U + MB - 1) / MB)), dim3(MB), 0, C.st,
+        // (a small grid: its blocks stride over the list, whose length -- usually a handful -- only the device knows)
+        hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)std::min<uint64_t>((C.U + MB - 1) / MB, 512)), dim3(MB), 0, C.st,
                            C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
                            C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
                            (const uint32_t*)C.fb.as<uint32_t>(), (const unsigned long long*)(C.fb_n + r), next_list, C.act_n + r + 1);
