@@ -101,7 +101,7 @@ def rows(path):
 def check_run_against_golden(run, case, outdir):
     """run: a finished mirge_amd.driver.MirgeRun whose tables were written to outdir."""
     exp = case["expected"]
-    for f in ("miR.Counts.csv", "miR.RPM.csv"):                     # byte-identical
+    for f in ("miR.Counts.csv", "miR.RPM.csv"):                     # byte-identical (to a reference run whose bowtie was the oracle: parity with bowtie itself unpinned)
         assert open(os.path.join(outdir, f)).read() == open(os.path.join(exp, f)).read(), f
     for f in ("mapped.csv", "unmapped.csv"):                        # identical as row sets
         assert rows(os.path.join(outdir, f)) == rows(os.path.join(exp, f)), f
