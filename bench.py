@@ -130,7 +130,7 @@ def main():
                          "annotStats and the per-unique tables then count a sequence once per shard that holds it)")
     ap.add_argument("--profile", default="human", choices=["human", "mouse", "medium", "small", "tiny"])
     ap.add_argument("--mixture", default="default", choices=["default", "isomir_rich", "realistic"])
-    ap.add_argument("--cpu-sample", type=int, default=300_000, help="reads of the same workload timed on the CPU (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads of the same workload timed on the CPU (0 = skip)")
     ap.add_argument("--chunk", type=int, default=1_000_000)
     ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end legs: FASTQ file -> count vectors (0 = skip)")
     ap.add_argument("--realistic-reads", type=int, default=20_000_000, help="reads of the extra line at the reference's published redundancy (0 = skip)")

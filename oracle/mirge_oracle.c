@@ -19,7 +19,7 @@ struct orc_lib {
     int32_t   n;
     char*     text;     /* concatenated, upper-cased, non-ACGT -> 'N' */
     uint64_t* offs;     /* n+1 */
-    /* indexed matcher: CSR over kb-mers of every reference (ACGT-only k-mers) */
+    /* indexed matcher: CSR over the kb-mer at every position of every reference */
     int32_t   kb;
     uint32_t* koff;     /* 4^kb + 1 */
     uint32_t* kref;     /* reference index of each occurrence */
@@ -41,10 +41,12 @@ static void lib_build_index(orc_lib* L) {
         for (int32_t r = 0; r < L->n; ++r) {
             const char* s = L->text + L->offs[r];
             int64_t len = (int64_t)(L->offs[r + 1] - L->offs[r]);
-            for (int64_t p = 0; p + kb <= len; ++p) {
-                uint64_t code = 0; int ok = 1;
-                for (int i = 0; i < kb; ++i) { int c = code_of(s[p + i]); if (c < 0) { ok = 0; break; } code = (code << 2) | (uint64_t)c; }
-                if (!ok) continue;
+            /* every position is entered, under its first kb bases with 'A' standing in for what lies beyond the
+               reference's end or is not A/C/G/T: a lookup by a shorter prefix (a seed piece shorter than kb) then finds
+               the positions near the end too; what the stand-ins let in by mistake fails the window check */
+            for (int64_t p = 0; p < len; ++p) {
+                uint64_t code = 0;
+                for (int i = 0; i < kb; ++i) { int c = p + i < len ? code_of(s[p + i]) : 0; if (c < 0) c = 0; code = (code << 2) | (uint64_t)c; }
                 if (pass == 0) { L->koff[code + 1]++; total++; }
                 else { uint32_t at = L->koff[code]++; L->kref[at] = (uint32_t)r; L->kpos[at] = (uint32_t)p; }
             }
@@ -227,17 +229,19 @@ void orc_match_indexed(const orc_lib* L, const char* read, int32_t len, const or
     int span = q.s, np = nA;
     if (q.l / nB > q.s / nA) { span = q.l; np = nB; }
     int kb = L->kb;
-    if (span / np < kb) { orc_match_brute(L, read, len, P, out); out->nhits = -1; return; }
+    if (span / np < 3) { orc_match_brute(L, read, len, P, out); out->nhits = -1; return; }
     /* candidate windows may repeat across pieces: max/min reductions do not care */
     for (int fw = 1; fw >= 0; --fw) {
         const char* r = q.r[fw];
         for (int p = 0; p < np; ++p) {
             int ps = (int)((int64_t)span * p / np), pe = (int)((int64_t)span * (p + 1) / np);   /* in READ coordinates */
             int qs = fw ? ps : q.l - pe;                       /* where that piece sits in the oriented read */
+            int kq = pe - ps < kb ? pe - ps : kb;              /* a piece shorter than the index k-mer: every k-mer it is a prefix of */
             uint64_t code = 0; int ok = 1;
-            for (int i = 0; i < kb; ++i) { int c = code_of(r[qs + i]); if (c < 0) { ok = 0; break; } code = (code << 2) | (uint64_t)c; }
+            for (int i = 0; i < kq; ++i) { int c = code_of(r[qs + i]); if (c < 0) { ok = 0; break; } code = (code << 2) | (uint64_t)c; }
             if (!ok) continue;                                  /* a piece holding a read N cannot be the exact one */
-            for (uint32_t at = L->koff[code]; at < L->koff[code + 1]; ++at) {
+            uint64_t b0 = code << (2 * (kb - kq)), b1 = (code + 1) << (2 * (kb - kq));
+            for (uint32_t at = L->koff[b0]; at < L->koff[b1]; ++at) {
                 int32_t ref = (int32_t)L->kref[at];
                 int64_t o = (int64_t)L->kpos[at] - qs;
                 int64_t rl = (int64_t)(L->offs[ref + 1] - L->offs[ref]);
