@@ -413,7 +413,14 @@ k_part_pass(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
 __global__ void __launch_bounds__(PT_BLOCK)
 k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ wt_in, const unsigned long long* __restrict__ n_in,
             const uint32_t* __restrict__ gslots, uint32_t gmask, uint64_t* ukeys, uint32_t U0,
-            uint32_t* coo_g, uint32_t* coo_c, unsigned long long* ctr) {
+            uint32_t* coo_g, uint32_t* coo_c, unsigned long long* ctr,
+            uint32_t* ll_short, uint32_t* ll_long, unsigned long long* ll_n, int ll_split) {
+    // ll_* (nullable): the new uniques' ids by length class, appended to two dense lists (ll_n = their lengths) --
+    // those shorter than ll_split nt and the others.  Rounds 1 and 2 of the reference cascade take one length class each
+    // (miRge.pl:326): walking "their" list they run with full lanes instead of a third / two thirds of every wave's.
+    // The two list counters are bumped by two other threads at the same moment as the rank counter: issued one after
+    // the other by one thread, the three round trips cost the kernel 0.19 ms (16 K partitions, each waiting for them).
+    __shared__ uint32_t s_lcnt[2], s_lbase[2];
     __shared__ uint64_t tk[PT_C2 * 2];
     __shared__ uint32_t towner[2 * PT_C2];
     __shared__ uint32_t tcnt[PT_C2];
@@ -428,6 +435,7 @@ k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
     for (uint32_t j = tid; j < nvalid * 2; j += PT_BLOCK) tk[j] = kin[j];
     for (uint32_t j = tid; j < 2u * PT_C2; j += PT_BLOCK) towner[j] = EMPTY;
     for (uint32_t j = tid; j < (uint32_t)PT_C2; j += PT_BLOCK) tcnt[j] = 0;
+    if (tid < 2) s_lcnt[tid] = 0;
     __syncthreads();
     uint32_t trep[PER];
 #pragma unroll
@@ -449,12 +457,12 @@ k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
     __syncthreads();
     // representatives -> (unique id, count) entries; ids of sequences an earlier sample brought come from the
     // cross-sample table, the others are appended (as k_collapse_emit)
-    uint32_t g[PER];
+    uint32_t g[PER], lrank[PER];
     uint32_t nrep = 0, nnew = 0;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
         const uint32_t idx = tid + e * PT_BLOCK;
-        g[e] = EMPTY;
+        g[e] = EMPTY; lrank[e] = 0;
         const bool rep = idx < nvalid && trep[e] == idx;
         if (rep && gslots) {
             const uint64_t k[2] = {tk[idx * 2], tk[idx * 2 + 1]};
@@ -467,6 +475,20 @@ k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
             }
         }
         nrep += rep; nnew += rep && g[e] == EMPTY;
+        if (ll_short) {
+            // ranks inside the block's two lists: one LDS atomic per wave and list (2048 threads on two words serialise)
+            const bool isnew = rep && g[e] == EMPTY;
+            const bool shrt = isnew && (int)(tk[(idx < nvalid ? idx : 0) * 2 + 1] >> 56) < ll_split;
+            const unsigned long long ms = __ballot(shrt), ml = __ballot(isnew && !shrt);
+            const unsigned long long below = (1ull << (tid & 63)) - 1;
+            uint32_t bs = 0, bl = 0;
+            if ((tid & 63) == 0) {
+                if (ms) bs = atomicAdd(&s_lcnt[0], (uint32_t)__popcll(ms));
+                if (ml) bl = atomicAdd(&s_lcnt[1], (uint32_t)__popcll(ml));
+            }
+            bs = __shfl(bs, 0); bl = __shfl(bl, 0);
+            lrank[e] = shrt ? bs + (uint32_t)__popcll(ms & below) : bl + (uint32_t)__popcll(ml & below);
+        }
         if (!rep) trep[e] = EMPTY;                              // from here on: EMPTY = not a representative
     }
     s_scan[tid] = nrep | (nnew << 16);
@@ -483,6 +505,7 @@ k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
         const unsigned long long old = atomicAdd(&ctr[0], ((unsigned long long)tnw << 32) | trp);
         s_base[0] = (uint32_t)old; s_base[1] = (uint32_t)(old >> 32);
     }
+    if (ll_short && tid < 2) s_lbase[tid] = s_lcnt[tid] ? (uint32_t)atomicAdd(&ll_n[tid], (unsigned long long)s_lcnt[tid]) : 0u;   // (s_lcnt is complete: the scan's barriers lie behind)
     __syncthreads();
     uint32_t prep = s_base[0] + (incl & 0xFFFF) - nrep, pnew = s_base[1] + (incl >> 16) - nnew;
 #pragma unroll
@@ -493,6 +516,10 @@ k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
         if (gg == EMPTY) {
             gg = U0 + pnew++;
             ukeys[(uint64_t)gg * 2] = tk[idx * 2]; ukeys[(uint64_t)gg * 2 + 1] = tk[idx * 2 + 1];
+            if (ll_short) {
+                if ((int)(tk[idx * 2 + 1] >> 56) < ll_split) ll_short[s_lbase[0] + lrank[e]] = gg;
+                else ll_long[s_lbase[1] + lrank[e]] = gg;
+            }
         }
         coo_g[prep] = gg; coo_c[prep] = tcnt[idx];
         ++prep;
@@ -1415,7 +1442,7 @@ __device__ __forceinline__ void finish_on_text(const uint64_t* __restrict__ ukey
 template <int KW, int RN>
 __device__ __forceinline__ void match_block(const uint32_t bid, const uint32_t n, const uint64_t* __restrict__ ukeys, uint8_t* ann_round, int32_t* ann_ref,
               uint8_t* ann_amb, const LibDev& L, const RoundDev& P, int thr, unsigned long long* stats,
-              const uint32_t* __restrict__ list, uint32_t* next_list, unsigned long long* next_n) {
+              const uint32_t* __restrict__ list, uint32_t* next_list, unsigned long long* next_n, const bool init) {
     // list (nullable) = the uniques no earlier round annotated, as left by the previous round's launch;
     // next_list (nullable) receives this round's survivors.  Dense lists keep the lanes busy in the
     // later rounds, where most of the table is already annotated.
@@ -1435,9 +1462,10 @@ __device__ __forceinline__ void match_block(const uint32_t bid, const uint32_t n
     // a load that waits for the state is a longer dependent chain for everyone else)
     uint8_t done_before = 0;
     if (u != EMPTY) {
-        // the first round of a cascade (always a walk over the whole table) leaves the "not annotated" state behind
-        // instead of reading it: the host fills none of the three arrays
-        if (RN == 0) { ann_round[u] = 0; ann_ref[u] = -1; ann_amb[u] = 0; }
+        // the first launch that meets a unique (round 1's walk over the whole table; rounds 1 and 2 when each walks its
+        // own length class, `init`) leaves the "not annotated" state behind instead of reading it: the host fills none
+        // of the three arrays
+        if (init) { ann_round[u] = 0; ann_ref[u] = -1; ann_amb[u] = 0; }
         else if (!list) done_before = ann_round[u];
 #pragma unroll
         for (int w = 0; w < KW; ++w) k[w] = ukeys[(uint64_t)u * KW + w];
@@ -1612,10 +1640,10 @@ __global__ void __launch_bounds__(MB, MG_MATCH_WAVES)
 k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref,
               uint8_t* ann_amb, LibDev L, RoundDev P, int thr, unsigned long long* stats,
               const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_n,
-              uint32_t* next_list, unsigned long long* next_n) {
-    const uint32_t n = list ? (uint32_t)*list_n : U;
+              uint32_t* next_list, unsigned long long* next_n, bool init) {
+    const uint32_t n = (list && list_n) ? (uint32_t)*list_n : U;          // (a list without a length word is as long as the table: EMPTY = a hole)
     for (uint32_t bid = blockIdx.x; (uint64_t)bid * MB < n; bid += gridDim.x) {
-        match_block<KW, RN>(bid, n, ukeys, ann_round, ann_ref, ann_amb, L, P, thr, stats, list, next_list, next_n);
+        match_block<KW, RN>(bid, n, ukeys, ann_round, ann_ref, ann_amb, L, P, thr, stats, list, next_list, next_n, init);
         __syncthreads();                                   // the block's LDS state is reused by its next piece of work
     }
 }
@@ -1648,7 +1676,7 @@ __global__ void __launch_bounds__(PB, MG_PROBE_WAVES)
 k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb,
               LibDev L, RoundDev P, RoundSch RS, unsigned long long* stats,
               const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_n,
-              uint32_t* next_list, unsigned long long* next_n, uint32_t* fb_list, unsigned long long* fb_n) {
+              uint32_t* next_list, unsigned long long* next_n, uint32_t* fb_list, unsigned long long* fb_n, bool init) {
     constexpr int PQ4 = ProbeQ<NS>::Q4, PQ64 = ProbeQ<NS>::Q64;
     __shared__ unsigned long long s_best[3 * PB];
     __shared__ uint64_t s_r0[PB], s_r1[PB];
@@ -1656,14 +1684,14 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     __shared__ uint32_t s_q4lo[PQ4], s_q4meta[PQ4], s_q64lo[PQ64], s_q64meta[PQ64];
     __shared__ uint32_t s_qn4, s_qn64, s_wcnt[2][PB / 64], s_base[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t n = list ? (uint32_t)*list_n : U;
+    const uint32_t n = (list && list_n) ? (uint32_t)*list_n : U;
     if (blockIdx.x * PB >= n) return;
     const uint32_t i = blockIdx.x * PB + tid;
     const uint32_t u = i < n ? (list ? list[i] : i) : EMPTY;
     uint64_t k[2] = {0, 0};
     uint8_t done_before = 0;
     if (u != EMPTY) {
-        if (RN == 0) { ann_round[u] = 0; ann_ref[u] = -1; ann_amb[u] = 0; }
+        if (init) { ann_round[u] = 0; ann_ref[u] = -1; ann_amb[u] = 0; }       // as in k_match_round
         else if (!list) done_before = ann_round[u];
         k[0] = ukeys[(uint64_t)u * 2]; k[1] = ukeys[(uint64_t)u * 2 + 1];
     }

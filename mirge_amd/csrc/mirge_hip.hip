@@ -114,6 +114,7 @@ struct Lib {
 };
 
 constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
+constexpr int LL_SPLIT = 26;                              // miRge.pl:326: round 1 takes length < 26, round 2 length > 25
 constexpr int LEN_BINS = MIRGE_MAX_READ_LEN + 1;          // read-length histogram rows (miRge.pl:315)
 
 struct Segment { int sample; uint64_t start, count; };
@@ -137,11 +138,15 @@ struct Class {
     uint32_t pend_n = 0; int pend_sample = 0; bool pending = false;     // a collapse launched, not yet finished
     bool pend_part = false; const uint64_t* pend_keys = nullptr; const uint32_t* pend_wt = nullptr;      // ... in partitioned form: its inputs, should it have to start over
     DevBuf pt_k1, pt_w1, pt_k2, pt_w2, pt_cur;                          // partitioned collapse: level-1 / level-2 regions, cursors + overflow word
+    // length-class lists (16-byte class): ids of the uniques shorter than LL_SPLIT nt / of the others, appended by
+    // k_part_fold.  Complete -- and walked by rounds 1 and 2 of the reference cascade -- as long as every unique since
+    // the last reset came through the partitioned form (ll_ok); ll_fresh: their counters were zeroed since that reset.
+    DevBuf ll[2], ll_ctr; bool ll_ok = true, ll_fresh = false;
     std::vector<Segment> segs;
-    void reset() { U = 0; coo_n = 0; gvalid = false; segs.clear(); }
+    void reset() { U = 0; coo_n = 0; gvalid = false; segs.clear(); ll_ok = true; ll_fresh = false; }
     void release() { ukeys.release(); coo_g.release(); coo_c.release(); gslots.release(); act[0].release(); act[1].release(); fb.release(); ann_round.release(); ann_ref.release(); ann_amb.release();
                      ws_lslots.release(); ws_cnt.release(); ws_cnt0.release(); ws_ctr.release();
-                     pt_k1.release(); pt_w1.release(); pt_k2.release(); pt_w2.release(); pt_cur.release(); }
+                     pt_k1.release(); pt_w1.release(); pt_k2.release(); pt_w2.release(); pt_cur.release(); ll[0].release(); ll[1].release(); ll_ctr.release(); }
 };
 
 // Verbatim uniques (kernels.h: match_long): reads no key can hold, collapsed by their exact string as miRge.pl:306 does.
@@ -512,6 +517,11 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
         }
         HIPCHK(c, hipMemsetAsync(C.pt_cur.p, 0, ncur * 8, st));
         HIPCHK(c, hipMemsetAsync(C.ws_ctr.p, 0, 64, st));
+        if (C.ll_ok) {
+            for (auto& b : C.ll) HIPCHK(c, b.ensure((C.U + n) * 4, true, C.U * 4, st));
+            HIPCHK(c, C.ll_ctr.ensure(64, false, 0, st));
+            if (!C.ll_fresh) { HIPCHK(c, hipMemsetAsync(C.ll_ctr.p, 0, 64, st)); C.ll_fresh = true; }
+        }
         unsigned long long* cur = C.pt_cur.as<unsigned long long>();
         unsigned long long* ovf = cur + ncur - 1;
         kt_begin(c, "collapse_part16", st);
@@ -526,7 +536,8 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
         hipLaunchKernelGGL(k_part_fold, dim3(PT_P1 * PT_P2), dim3(PT_BLOCK), 0, st, C.pt_k2.as<uint64_t>(), C.pt_w2.as<uint32_t>(),
                            (const unsigned long long*)(cur + PT_P1), use_g ? C.gslots.as<uint32_t>() : (const uint32_t*)nullptr,
                            (uint32_t)(C.gcap ? C.gcap - 1 : 0), C.ukeys.as<uint64_t>(), (uint32_t)C.U,
-                           C.coo_g.as<uint32_t>() + C.coo_n, C.coo_c.as<uint32_t>() + C.coo_n, C.ws_ctr.as<unsigned long long>());
+                           C.coo_g.as<uint32_t>() + C.coo_n, C.coo_c.as<uint32_t>() + C.coo_n, C.ws_ctr.as<unsigned long long>(),
+                           C.ll_ok ? C.ll[0].as<uint32_t>() : (uint32_t*)nullptr, C.ll[1].as<uint32_t>(), C.ll_ctr.as<unsigned long long>(), LL_SPLIT);
         kt_end(c, "collapse_fold16", 0, st);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(C.h_ctr, C.ws_ctr.p, 16, hipMemcpyDeviceToHost, st));
@@ -534,6 +545,7 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
         C.pend_part = true;
         return MIRGE_OK;
     }
+    C.ll_ok = false;                                         // the table form keeps no length-class lists
     uint64_t capL = pow2_at_least((uint64_t)n + n / 4);      // load <= 0.8 even if every read is distinct; smaller table = more of it cache-resident
     if (capL > (1ull << 32)) {                               // slots are addressed by 32 hash bits
         if ((uint64_t)n > 3ull << 30) return fail(c, MIRGE_E_LIMIT, "more than 3 * 2^30 reads in one collapse call");
@@ -1111,30 +1123,45 @@ int shard_import(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, u
 }
 
 // ---- cascade + count vectors
+// do rounds 1 and 2 each walk their own length class (Class::ll) ?
+bool ll_rounds(const mirge_ctx* c, const Class& C) {
+    if (C.KW != 2 || !C.ll_ok || !C.ll_fresh || C.U == 0 || c->n_rounds < 2) return false;
+    if (const char* e = getenv("MIRGE_LEN_LISTS")) { if (atoi(e) == 0) return false; }       // A/B aid
+    const mirge_round &a = c->rounds[0], &b = c->rounds[1];
+    return a.len_lt == LL_SPLIT && a.len_gt == 0 && b.len_gt == LL_SPLIT - 1 && b.len_lt == 0;
+}
 template <int KW, int RN>
 void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, int thr, int r) {
-    const uint32_t* list = r <= 1 ? (const uint32_t*)nullptr : C.act[(r + 1) & 1].as<uint32_t>();      // round 1 keeps no list: nearly everything survives it
-    uint32_t* next_list = (r >= 1 && r + 1 < c->n_rounds) ? C.act[r & 1].as<uint32_t>() : (uint32_t*)nullptr;
+    // round 1 keeps no survivor list (nearly everything survives it), round 2 scans the table and writes the first one;
+    // with length-class lists rounds 1 and 2 walk one each (full lanes, and both meet their uniques for the first
+    // time: init), and round 3 is the one that scans the table -- 93 % of it is still unannotated by then
+    const bool ll = ll_rounds(c, C);
+    const uint32_t* list = r <= 1 ? (ll ? C.ll[r].as<uint32_t>() : (const uint32_t*)nullptr)
+                                  : (r == 2 && ll ? (const uint32_t*)nullptr : C.act[(r + 1) & 1].as<uint32_t>());
+    const unsigned long long* list_n = (r <= 1 && ll) ? C.ll_ctr.as<unsigned long long>() + r : C.act_n + r;
+    const bool writes = ll ? r >= 2 : r >= 1;
+    uint32_t* next_list = (writes && r + 1 < c->n_rounds) ? C.act[r & 1].as<uint32_t>() : (uint32_t*)nullptr;
+    const bool init = r == 0 || (r == 1 && ll);
     if (KW == 2 && probe_round(L, P)) {
         // the probe path (kernels.h: k_probe_round) for what the slot tables can serve, then the generic kernel over the
-        // reads it handed on -- its grid covers the worst case, blocks beyond the list's length leave at once
+        // reads it handed on
         const RoundSch RS = round_schemes(L, P);
         auto kern = RS.n == 0 ? k_probe_round<RN, 0> : (RS.n == 1 ? k_probe_round<RN, 1> : k_probe_round<RN, ROUND_SCHEMES>);
         hipLaunchKernelGGL(kern, dim3((uint32_t)((C.U + PB - 1) / PB)), dim3(PB), 0, C.st,
                            C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), C.ann_amb.as<uint8_t>(),
-                           L, P, RS, c->d_stats + (size_t)r * STAT_WORDS, list, C.act_n + r, next_list, C.act_n + r + 1,
-                           C.fb.as<uint32_t>(), C.fb_n + r);
+                           L, P, RS, c->d_stats + (size_t)r * STAT_WORDS, list, list_n, next_list, C.act_n + r + 1,
+                           C.fb.as<uint32_t>(), C.fb_n + r, init);
         // (a small grid: its blocks stride over the list, whose length -- usually a handful -- only the device knows)
         hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)std::min<uint64_t>((C.U + MB - 1) / MB, 512)), dim3(MB), 0, C.st,
                            C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
                            C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
-                           (const uint32_t*)C.fb.as<uint32_t>(), (const unsigned long long*)(C.fb_n + r), next_list, C.act_n + r + 1);
+                           (const uint32_t*)C.fb.as<uint32_t>(), (const unsigned long long*)(C.fb_n + r), next_list, C.act_n + r + 1, false);
         return;
     }
     hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((C.U + MB - 1) / MB)), dim3(MB), 0, C.st,
                        C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
                        C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
-                       list, C.act_n + r, next_list, C.act_n + r + 1);
+                       list, list_n, next_list, C.act_n + r + 1, init);
 }
 
 // the round number is a template parameter only so that every round is its own kernel symbol in a
