@@ -170,9 +170,12 @@ def summarize(counts, ulen, ann_round, ann_ref, M, maxlen=128, rounds=None):
     return dict(quant=quant, iscan=iscan, cat=cat, tuniq=tuniq, lenhist=lenhist)
 
 
-def run_path(libs, sample_reads, rounds=MIRGE_ROUNDS, use_index=True, nthreads=1, maxlen=128):
+def run_path(libs, sample_reads, rounds=MIRGE_ROUNDS, use_index=True, nthreads=1, maxlen=128, want_uniques=True):
     """Whole hot path on the CPU: sample_reads = list (one per sample) of list[str] or (seqs, lens).
-    Returns dict with uniques (list[str]), counts [U,S], ann_*, stats and the count vectors."""
+    Returns dict with uniques (list[str]; None with want_uniques=False: a 10M-entry Python list costs more than the C
+    code it feeds), counts [U,S], ann_*, stats, the count vectors, and c_seconds = wall time spent inside the three C
+    calls (collapse, cascade, count vectors) -- what bench.py's cpu_baseline leg reports."""
+    import time
     texts, offs_l, sample_of = [], [], []
     for s, sr in enumerate(sample_reads):
         t, o = _concat(*sr) if isinstance(sr, tuple) else _concat(sr)
@@ -182,18 +185,37 @@ def run_path(libs, sample_reads, rounds=MIRGE_ROUNDS, use_index=True, nthreads=1
     offs = np.zeros(len(lens) + 1, dtype=np.uint64); np.cumsum(lens, out=offs[1:])
     sample_of = np.concatenate(sample_of) if sample_of else np.zeros(0, np.int64)
     n = len(lens)
+    if len(text) == 0:
+        text = np.zeros(1, np.uint8)
     uid = np.zeros(max(n, 1), dtype=np.int64); rep = np.zeros(max(n, 1), dtype=np.int64)
+    t0 = time.perf_counter()
     U = lib().orc_collapse(n, text.ctypes.data, offs.ctypes.data, uid.ctypes.data, rep.ctypes.data)
+    c_seconds = time.perf_counter() - t0
     uid = uid[:n]; rep = rep[:U]
     S = len(sample_reads)
     counts = np.zeros((U, S), dtype=np.uint32)
     np.add.at(counts, (uid, sample_of), 1)
     ulen = lens[rep].astype(np.int32)
     uo = offs[rep].astype(np.int64)
-    uniques = [text[uo[i]:uo[i] + ulen[i]].tobytes().decode() for i in range(U)]
-    ann_round, ann_ref, ann_amb, stats = cascade(libs, uniques, rounds=rounds, use_index=use_index, nthreads=nthreads)
+    # the uniques' text, gathered without a Python loop
+    uoffs = np.zeros(U + 1, dtype=np.uint64); np.cumsum(ulen, out=uoffs[1:])
+    tot = int(uoffs[U])
+    src = np.repeat(uo - uoffs[:-1].astype(np.int64), ulen) + np.arange(tot, dtype=np.int64)
+    utext = np.ascontiguousarray(text[src]) if tot else np.zeros(1, np.uint8)
+    arr = (C.c_void_p * len(libs))(*[l._h for l in libs])
+    ra = rounds_array(rounds)
+    ann_round = np.zeros(max(U, 1), dtype=np.int8); ann_ref = np.zeros(max(U, 1), dtype=np.int32); ann_amb = np.zeros(max(U, 1), dtype=np.int8)
+    stats = np.zeros((len(rounds), 2), dtype=np.int64)
+    t0 = time.perf_counter()
+    lib().orc_cascade(arr, U, utext.ctypes.data, uoffs.ctypes.data, len(rounds), ra, int(use_index), int(nthreads),
+                      ann_round.ctypes.data, ann_ref.ctypes.data, ann_amb.ctypes.data, stats.ctypes.data)
+    c_seconds += time.perf_counter() - t0
+    ann_round, ann_ref, ann_amb = ann_round[:U], ann_ref[:U], ann_amb[:U]
+    t0 = time.perf_counter()
     out = summarize(counts, ulen, ann_round, ann_ref, libs[0].n, maxlen=maxlen,
                     rounds=None if list(rounds) == list(MIRGE_ROUNDS) else rounds)
+    c_seconds += time.perf_counter() - t0
+    uniques = [utext[int(uoffs[i]):int(uoffs[i + 1])].tobytes().decode() for i in range(U)] if want_uniques else None
     out.update(uniques=uniques, counts=counts, ulen=ulen, ann_round=ann_round, ann_ref=ann_ref, ann_amb=ann_amb,
-               stats=stats, uid=uid)
+               stats=stats, uid=uid, c_seconds=c_seconds)
     return out

@@ -8,7 +8,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # steps start at the k_collapse_local<2 launches
-marks = [i for i, r in enumerate(rows) if "k_collapse_local<2" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "k_part_pass<64" in r["Kernel_Name"] or "k_collapse_local<2" in r["Kernel_Name"]]
 step = rows[marks[-3]:marks[-2]]          # a timed step (the last launch belongs to the invariants pass)
 t0 = int(step[0]["Start_Timestamp"]); prev_end = t0
 for r in step:
