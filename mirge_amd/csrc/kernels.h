@@ -1749,25 +1749,31 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     // lookups two at a time: both occupancy words, then both slots, then the candidates.  The first pair is
     // unconditional; later ones are skipped where what this thread has found itself already rules them out.
     const bool ubits = tab_bits(R.tab);
-    for (int i0 = 0; i0 < PROBE_MAX_LOOK; i0 += 2) {
-        uint32_t slot[2], b[2]; int ps[2]; bool have[2];
+#ifndef MG_PROBE_STEP
+#define MG_PROBE_STEP 2
+#endif
+    constexpr int PW = MG_PROBE_STEP;                          // lookups in flight per thread
+    for (int i0 = 0; i0 < PROBE_MAX_LOOK; i0 += PW) {
+        uint32_t slot[PW], b[PW]; int ps[PW]; bool have[PW];
+        bool any = false;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < PW; ++j) {
             have[j] = run && !fb && i0 + j < R.nlook && probe_needed(R, P, i0 + j, Bst.score);
             slot[j] = 0; b[j] = 0; ps[j] = 0;
             if (have[j]) probe_lookup(R, L, i0 + j, slot[j], b[j], ps[j]);
+            any = any || have[j];
         }
-        if (i0 && !__any(have[0] || have[1])) break;
-        uint32_t wd[2];
+        if (i0 && !__any(any)) break;
+        uint32_t wd[PW];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) wd[j] = (have[j] && ubits) ? L.sbits[b[j] >> 5] : 0xFFFFFFFFu;
+        for (int j = 0; j < PW; ++j) wd[j] = (have[j] && ubits) ? L.sbits[b[j] >> 5] : 0xFFFFFFFFu;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) have[j] = have[j] && ((wd[j] >> (b[j] & 31)) & 1);
-        PEnt e[2];
+        for (int j = 0; j < PW; ++j) have[j] = have[j] && ((wd[j] >> (b[j] & 31)) & 1);
+        PEnt e[PW];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { e[j].pos = SLOT_EMPTY; if (have[j]) e[j] = load_pent(L.slots, slot[j]); }
+        for (int j = 0; j < PW; ++j) { e[j].pos = SLOT_EMPTY; if (have[j]) e[j] = load_pent(L.slots, slot[j]); }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) if (have[j]) take(e[j], ps[j]);
+        for (int j = 0; j < PW; ++j) if (have[j]) take(e[j], ps[j]);
     }
     __syncthreads();
 
