@@ -139,7 +139,10 @@ int32_t     mirge_collapse_ascii_dev(mirge_ctx*, const void* d_seqs, uint32_t wi
  * unspecified. */
 int32_t     mirge_pack_dev(mirge_ctx*, const void* d_seqs, uint32_t width, const void* d_lens, uint64_t n,
                            void* d_keys16, uint64_t* n16, void* d_keys48, uint64_t* n48);
-/* Collapse of device-resident packed keys (the configuration bench.py times). */
+/* Collapse of device-resident packed keys (the configuration bench.py times).  The keys are TRUSTED: built by
+ * mirge_pack_dev or to the formats of keys.h (length byte <= 56 / 124, zero bits above 2 * length, N mask within the
+ * length).  They are not validated on entry -- a pass over them would cost what a collapse pass costs; a malformed key
+ * collapses as its own sequence and its length is clamped wherever it is decoded. */
 int32_t     mirge_collapse_packed_dev(mirge_ctx*, const void* d_keys16, uint64_t n16,
                                       const void* d_keys48, uint64_t n48, int32_t sample);
 
