@@ -215,12 +215,20 @@ def main():
         fence()
         t0 = time.perf_counter()
         dev_ms, kts = [], []
+        raw = []
         for _ in range(n_steps):
             step(**kw)
             tm = ctx.last_timing(); dev_ms.append(tm["collapse_ms"] + tm["annotate_ms"] + tm["counts_ms"])
-            kts.append(ctx.kernel_times())
+            n, names, ms, by = ctx.kernel_times_raw()            # (the events of this step are re-recorded by the next one)
+            raw.append((n, list(ms[:n]), list(by[:n]), [names[i] for i in range(n)] if not raw else None))
         fence()
-        return time.perf_counter() - t0, dev_ms, kts
+        el = time.perf_counter() - t0
+        nm = [x.decode() for x in raw[0][3]] if raw else []
+        for n, ms, by, names in raw:
+            if names is not None:
+                nm = [x.decode() for x in names]
+            kts.append({nm[i]: (ms[i], by[i]) for i in range(min(n, len(nm)))})
+        return el, dev_ms, kts
 
     for _ in range(args.warmup):
         step()

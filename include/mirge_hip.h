@@ -145,6 +145,9 @@ int32_t     mirge_pack_dev(mirge_ctx*, const void* d_seqs, uint32_t width, const
  * collapses as its own sequence and its length is clamped wherever it is decoded. */
 int32_t     mirge_collapse_packed_dev(mirge_ctx*, const void* d_keys16, uint64_t n16,
                                       const void* d_keys48, uint64_t n48, int32_t sample);
+/* For callers that build keys themselves: checks both streams against the formats (one streaming pass);
+ * MIRGE_E_FORMAT names the first malformed key. */
+int32_t     mirge_validate_keys_dev(mirge_ctx*, const void* d_keys16, uint64_t n16, const void* d_keys48, uint64_t n48);
 
 /* NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate device memory -- code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc: the collapse step of mirge_collapse_packed_dev for one stream

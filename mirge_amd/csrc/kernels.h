@@ -310,6 +310,42 @@ k_collapse_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ 
     }
 }
 
+// A caller-built key stream checked against the formats of keys.h (mirge_validate_keys_dev): length byte within the
+// class's limit, no bits above the sequence, N mask within the length and a zero code under every N.  flag[0] = 1 +
+// index of the first offender found (0 = none), by atomicMin on the index.
+MG_HD uint64_t spread32_pair(uint64_t m, int half) {       // 32 mask bits (low or high half of m) -> even bit positions of a word
+    uint64_t x = (uint32_t)(m >> (32 * half));
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull; x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full; x = (x | (x << 2)) & 0x3333333333333333ull;
+    return (x | (x << 1)) & 0x5555555555555555ull;
+}
+template <int KW>
+__global__ void __launch_bounds__(256)
+k_validate_keys(const uint64_t* __restrict__ keys, uint64_t n, unsigned long long* flag) {
+    constexpr int SW = KeyTraits<KW>::SW, NW = KeyTraits<KW>::NW;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k[KW];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) k[w] = keys[i * KW + w];
+    const int len = (int)(k[SW - 1] >> 56);
+    bool bad = len > KeyTraits<KW>::MAXLEN;
+    k[SW - 1] &= ones(56);
+#pragma unroll
+    for (int w = 0; w < SW; ++w) bad = bad || (k[w] & ~ones(2 * len - 64 * w)) != 0;
+    if (KeyTraits<KW>::HASN) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const uint64_t nm = k[SW + w];
+            bad = bad || (nm & ~ones(len - 64 * w)) != 0;
+            // the two sequence words under this mask word must hold code 0 wherever it is set
+            const uint64_t lo = spread32_pair(nm, 0), hi = spread32_pair(nm, 1);
+            bad = bad || (k[2 * w] & (lo | (lo << 1))) != 0 || (2 * w + 1 < SW && (k[2 * w + 1] & (hi | (hi << 1))) != 0);
+        }
+    }
+    if (bad) atomicMin(flag, (unsigned long long)i + 1);
+}
+
 // ------------------------------------------------------------------------------------------
 // Partitioned collapse (16-byte keys; BASELINE.json's "LDS-staged" collapse in hash form).  The table form above pays
 // one device-scope compare-and-swap and ~3 random lines per distinct key; at the bench's U/N = 0.55 that is what its

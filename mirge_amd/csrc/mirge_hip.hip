@@ -1729,6 +1729,22 @@ int32_t mirge_collapse_ascii_dev(mirge_ctx* c, const void* d_seqs, uint32_t widt
     return collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
 }
 
+int32_t mirge_validate_keys_dev(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, uint64_t n48) {
+    if (!c || (n16 && !d16) || (n48 && !d48)) return c ? fail(c, MIRGE_E_ARG, "null device pointer") : MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->ctr.ensure(128, false, 0, c->st));
+    HIPCHK(c, hipMemsetAsync(c->ctr.p, 0xFF, 16, c->st));
+    unsigned long long* f = c->ctr.as<unsigned long long>();
+    if (n16) hipLaunchKernelGGL((k_validate_keys<2>), dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, c->st, (const uint64_t*)d16, n16, f);
+    if (n48) hipLaunchKernelGGL((k_validate_keys<6>), dim3((uint32_t)((n48 + 255) / 256)), dim3(256), 0, c->st, (const uint64_t*)d48, n48, f + 1);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->ctr.p, 16, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (c->h_ctr[0] != ~0ull) return fail(c, MIRGE_E_FORMAT, "16-byte key " + std::to_string(c->h_ctr[0] - 1) + " is malformed (length byte, bits above the sequence)");
+    if (c->h_ctr[1] != ~0ull) return fail(c, MIRGE_E_FORMAT, "48-byte key " + std::to_string(c->h_ctr[1] - 1) + " is malformed (length byte, bits above the sequence, N mask)");
+    return MIRGE_OK;
+}
+
 int32_t mirge_collapse_packed_dev(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, uint64_t n48, int32_t sample) {
     if (!c || (n16 && !d16) || (n48 && !d48)) return c ? fail(c, MIRGE_E_ARG, "null device pointer") : MIRGE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));

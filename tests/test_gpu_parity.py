@@ -134,6 +134,35 @@ def test_errors_fail_loudly():
         capi.Context("/nonexistent/species", 1, 0)
 
 
+def test_validate_keys_names_the_malformed_key():
+    """mirge_validate_keys_dev: keys a caller built itself, against the formats of keys.h."""
+    import torch
+    def key16(seq, length=None):
+        w = [0, 0]
+        for i, ch in enumerate(seq):
+            w[i >> 5] |= "ACGT".index(ch) << (2 * (i & 31))
+        w[1] |= (len(seq) if length is None else length) << 56
+        return [x - (1 << 64) if x >= (1 << 63) else x for x in w]
+    good = [key16("ACGTACGTACGTACGTAC"), key16("T" * 56), key16("")]
+    with capi.Context(None, 1, 0) as ctx:
+        k = torch.tensor(good, dtype=torch.int64, device="cuda")
+        ctx.validate_keys_dev(k.data_ptr(), len(good), None, 0)
+        for bad, what in ((key16("ACGT", 57), "length"), (key16("ACGTACGT", 4), "bits above")):
+            k = torch.tensor(good + [bad], dtype=torch.int64, device="cuda")
+            with pytest.raises(capi.MirgeError) as e:
+                ctx.validate_keys_dev(k.data_ptr(), len(good) + 1, None, 0)
+            assert e.value.code == capi.MIRGE_E_FORMAT and "key 3" in str(e.value), what
+        # 48-byte keys: N mask beyond the length, and a non-zero code under an N
+        base = [0, 0, 0, 5 << 56, 0, 0]                                               # "AAAAA"
+        for bad in ([0, 0, 0, 5 << 56, 1 << 7, 0], [3 << 2, 0, 0, 5 << 56, 1 << 1, 0]):
+            k = torch.tensor([base, bad], dtype=torch.int64, device="cuda")
+            with pytest.raises(capi.MirgeError) as e:
+                ctx.validate_keys_dev(None, 0, k.data_ptr(), 2)
+            assert e.value.code == capi.MIRGE_E_FORMAT and "key 1" in str(e.value)
+        ok = torch.tensor([base, [0, 0, 0, 5 << 56, 1 << 1, 0]], dtype=torch.int64, device="cuda")
+        ctx.validate_keys_dev(None, 0, ok.data_ptr(), 2)
+
+
 def test_device_resident_path_and_reset(oracle):
     """The configuration bench.py times: ASCII matrix resident in HBM -> mirge_pack_dev ->
     mirge_collapse_packed_dev -> annotate, twice through mirge_reset (second run smaller)."""
@@ -149,6 +178,7 @@ def test_device_resident_path_and_reset(oracle):
             torch.cuda.synchronize()
             n16, n48 = ctx.pack_dev(d_seqs.data_ptr(), seqs.shape[1], d_lens.data_ptr(), n, k16.data_ptr(), k48.data_ptr())
             assert n16 + n48 == n and n48 == int(((seqs == ord("N")).any(axis=1)).sum())
+            ctx.validate_keys_dev(k16.data_ptr(), n16, k48.data_ptr(), n48)          # what the library packs passes its own check
             ctx.reset()
             ctx.collapse_packed_dev(k16.data_ptr(), n16, k48.data_ptr(), n48, 0)
             ctx.annotate()
