@@ -145,6 +145,12 @@ int32_t     mirge_pack_dev(mirge_ctx*, const void* d_seqs, uint32_t width, const
  * collapses as its own sequence and its length is clamped wherever it is decoded. */
 int32_t     mirge_collapse_packed_dev(mirge_ctx*, const void* d_keys16, uint64_t n16,
                                       const void* d_keys48, uint64_t n48, int32_t sample);
+/* mirge_collapse_packed_dev + mirge_annotate of one sample as ONE call: the cascade is queued behind the collapse
+ * without the host waiting in between to learn the unique count (the launches are sized by an upper bound and read
+ * the count on the device), which is worth ~0.1 ms of idle device per call.  The key buffers need to stay valid only
+ * for the duration of the call.  Results as after mirge_annotate. */
+int32_t     mirge_collapse_annotate_packed_dev(mirge_ctx*, const void* d_keys16, uint64_t n16,
+                                               const void* d_keys48, uint64_t n48, int32_t sample);
 /* For callers that build keys themselves: checks both streams against the formats (one streaming pass);
  * MIRGE_E_FORMAT names the first malformed key. */
 int32_t     mirge_validate_keys_dev(mirge_ctx*, const void* d_keys16, uint64_t n16, const void* d_keys48, uint64_t n48);

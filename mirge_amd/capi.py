@@ -26,7 +26,7 @@ EXPORTS = [
     "mirge_shard_export_sizes", "mirge_shard_export", "mirge_shard_import",
     "mirge_collapse_fastq", "mirge_collapse_fastq_mem", "mirge_collapse_fastq_dev", "mirge_collapse_seqs", "mirge_collapse_ascii_dev", "mirge_pack_dev",
     "mirge_collapse_packed_dev", "mirge_annotate", "mirge_round_stats", "mirge_counts", "mirge_counts_flat_len",
-    "mirge_counts_flat_get", "mirge_counts_flat_set", "mirge_counts_flat_get_dev", "mirge_counts_flat_set_dev", "mirge_validate_keys_dev", "mirge_n_unique", "mirge_max_unique_len", "mirge_unique", "mirge_export_uniques",
+    "mirge_counts_flat_get", "mirge_counts_flat_set", "mirge_counts_flat_get_dev", "mirge_counts_flat_set_dev", "mirge_validate_keys_dev", "mirge_collapse_annotate_packed_dev", "mirge_n_unique", "mirge_max_unique_len", "mirge_unique", "mirge_export_uniques",
     "mirge_verb_export_size", "mirge_verb_export", "mirge_verb_clear", "mirge_verb_import",
     "mirge_n_counts", "mirge_export_counts", "mirge_last_timing", "mirge_kernel_times", "mirge_write_tables",
     "mirge_collapse_keys16_noalloc",
@@ -101,6 +101,7 @@ def load():
     L.mirge_n_unique.restype = u64; L.mirge_n_unique.argtypes = [vp]
     L.mirge_max_unique_len.restype = u32; L.mirge_max_unique_len.argtypes = [vp]
     L.mirge_validate_keys_dev.argtypes = [vp, vp, u64, vp, u64]
+    L.mirge_collapse_annotate_packed_dev.argtypes = [vp, vp, u64, vp, u64, i32]
     L.mirge_verb_export_size.restype = u64; L.mirge_verb_export_size.argtypes = [vp]
     L.mirge_verb_export.argtypes = [vp, vp]
     L.mirge_verb_clear.argtypes = [vp]
@@ -244,6 +245,9 @@ class Context:
         if len(text) == 0:
             text = np.zeros(1, dtype=np.uint8)
         self._chk(self.L.mirge_collapse_seqs(self.h, text.ctypes.data, offs.ctypes.data, len(lens), sample))
+
+    def collapse_annotate_packed_dev(self, d16, n16, d48, n48, sample):
+        self._chk(self.L.mirge_collapse_annotate_packed_dev(self.h, d16, n16, d48, n48, sample))
 
     def validate_keys_dev(self, d16, n16, d48, n48):
         self._chk(self.L.mirge_validate_keys_dev(self.h, d16, n16, d48, n48))

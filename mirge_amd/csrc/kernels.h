@@ -1676,7 +1676,11 @@ __global__ void __launch_bounds__(MB, MG_MATCH_WAVES)
 k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref,
               uint8_t* ann_amb, LibDev L, RoundDev P, int thr, unsigned long long* stats,
               const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_n,
-              uint32_t* next_list, unsigned long long* next_n, bool init) {
+              uint32_t* next_list, unsigned long long* next_n, bool init,
+              const unsigned long long* __restrict__ U_dev, uint32_t U0) {
+    // U_dev (nullable): the table's size is still on the device -- U0 uniques + the new ones of a collapse whose packed
+    // rank counter (new uniques in its high half) the host has not read yet; U is then an upper bound (grid sizing)
+    if (U_dev) U = U0 + (uint32_t)(*U_dev >> 32);
     const uint32_t n = (list && list_n) ? (uint32_t)*list_n : U;          // (a list without a length word is as long as the table: EMPTY = a hole)
     for (uint32_t bid = blockIdx.x; (uint64_t)bid * MB < n; bid += gridDim.x) {
         match_block<KW, RN>(bid, n, ukeys, ann_round, ann_ref, ann_amb, L, P, thr, stats, list, next_list, next_n, init);
@@ -1712,8 +1716,10 @@ __global__ void __launch_bounds__(PB, MG_PROBE_WAVES)
 k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb,
               LibDev L, RoundDev P, RoundSch RS, unsigned long long* stats,
               const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_n,
-              uint32_t* next_list, unsigned long long* next_n, uint32_t* fb_list, unsigned long long* fb_n, bool init) {
+              uint32_t* next_list, unsigned long long* next_n, uint32_t* fb_list, unsigned long long* fb_n, bool init,
+              const unsigned long long* __restrict__ U_dev, uint32_t U0) {
     constexpr int PQ4 = ProbeQ<NS>::Q4, PQ64 = ProbeQ<NS>::Q64;
+    if (U_dev) U = U0 + (uint32_t)(*U_dev >> 32);               // as in k_match_round
     __shared__ unsigned long long s_best[3 * PB];
     __shared__ uint64_t s_r0[PB], s_r1[PB];
     __shared__ uint32_t s_ls[PB];                // l | s << 8
@@ -1892,8 +1898,10 @@ __global__ void __launch_bounds__(256)
 k_counts(const uint32_t* __restrict__ coo_g, const uint32_t* __restrict__ coo_c, uint32_t n, int sample, int S,
          const uint64_t* __restrict__ ukeys, const uint8_t* __restrict__ ann_round, const int32_t* __restrict__ ann_ref,
          int M, uint32_t round_libs, uint32_t iscan_rounds, unsigned long long* quant, unsigned long long* iscan,
-         unsigned long long* cat, unsigned long long* lenhist, unsigned long long* tuniq) {
+         unsigned long long* cat, unsigned long long* lenhist, unsigned long long* tuniq,
+         const unsigned long long* __restrict__ n_dev) {
     extern __shared__ unsigned long long s_dyn[];
+    if (n_dev) n = (uint32_t)(*n_dev & 0xFFFFFFFFull);          // the entry count is still on the device (low half of the collapse's rank counter); n was an upper bound
     __shared__ unsigned long long s_cat[5];
     __shared__ unsigned long long s_len[128];
     __shared__ unsigned long long s_tu;

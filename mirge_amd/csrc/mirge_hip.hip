@@ -180,6 +180,7 @@ struct mirge_ctx {
     int S = 1;
     hipStream_t st = nullptr, st2 = nullptr;        // st: everything; st2: the 48-byte key class inside collapse_packed / annotate
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_c[2] = {nullptr, nullptr};           // timing marks of the last collapse call (its own pair: a fused call runs the cascade before they are read)
     hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};   // timing marks of the last collapse / cascade call (made once: no per-call create, no leak on an error return)
     std::string err;
     Lib libs[MIRGE_N_LIBS];
@@ -627,8 +628,12 @@ int collapse_finish(mirge_ctx* c, Class& C, const char* tagB) {
     return MIRGE_OK;
 }
 
-// both classes of one sample: the 16-byte class on st, the 48-byte class on st2, side by side
-int collapse_both(mirge_ctx* c, const uint64_t* d16, uint64_t n16, const uint32_t* w16, const uint64_t* d48, uint64_t n48, const uint32_t* w48, int sample) {
+// both classes of one sample: the 16-byte class on st, the 48-byte class on st2, side by side.
+// defer: everything is queued and nothing is waited for -- the unique counts stay on the device (Class::pending), the
+// cascade is queued behind (annotate() sizes its launches by upper bounds and reads the counts there), and
+// collapse_settle() does the bookkeeping once the host has waited for the cascade anyway.
+int collapse_both(mirge_ctx* c, const uint64_t* d16, uint64_t n16, const uint32_t* w16, const uint64_t* d48, uint64_t n48, const uint32_t* w48, int sample,
+                  bool defer = false) {
     int rc = fork_st2(c);                                  // the inputs were produced on st
     if (!rc) rc = collapse_launch<2>(c, c->cls[0], d16, n16, sample, "collapse_local16", "collapse_emit16", w16);
     if (!rc) rc = collapse_launch<6>(c, c->cls[1], d48, n48, sample, "collapse_local48", "collapse_emit48", w48);
@@ -637,22 +642,35 @@ int collapse_both(mirge_ctx* c, const uint64_t* d16, uint64_t n16, const uint32_
         (void)hipStreamSynchronize(c->st); (void)hipStreamSynchronize(c->st2);
         return rc;
     }
+    if (defer) return join_st2(c);
     rc = collapse_finish<2>(c, c->cls[0], "collapse_emit16");
     int r1 = collapse_finish<6>(c, c->cls[1], "collapse_emit48");
     if (!rc) rc = r1;
     if (!rc) rc = join_st2(c);
     return rc;
 }
+// a deferred collapse whose kernels are known to have finished: the two halves' bookkeeping.  reran: a partitioned
+// collapse had overrun and the sample went through the table form just now (whatever was computed from the first
+// attempt's output is void).
+int collapse_settle(mirge_ctx* c, bool& reran) {
+    reran = c->cls[0].pending && c->cls[0].pend_n && c->cls[0].pend_part && c->cls[0].h_ctr[2];
+    int rc = collapse_finish<2>(c, c->cls[0], "collapse_emit16");
+    int r1 = collapse_finish<6>(c, c->cls[1], "collapse_emit48");
+    if (!rc) rc = r1;
+    float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_c[0], c->ev_c[1]); c->collapse_ms = ms;
+    return rc;
+}
 
-int collapse_packed(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, uint64_t n48, int sample) {
+int collapse_packed(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, uint64_t n48, int sample, bool defer = false) {
     if (sample < 0 || sample >= c->S) return fail(c, MIRGE_E_ARG, "sample index out of range");
     c->annotated = false; c->counts_valid = false; c->host_valid = false;
     kt_clear(c, "collapse");
-    hipEvent_t a = c->ev_t[0], b = c->ev_t[1];
+    hipEvent_t a = c->ev_c[0], b = c->ev_c[1];
     HIPCHK(c, hipEventRecord(a, c->st));
-    int rc = collapse_both(c, (const uint64_t*)d16, n16, nullptr, (const uint64_t*)d48, n48, nullptr, sample);
+    int rc = collapse_both(c, (const uint64_t*)d16, n16, nullptr, (const uint64_t*)d48, n48, nullptr, sample, defer);
     if (!rc) {
         HIPCHK(c, hipEventRecord(b, c->st));
+        if (defer) return MIRGE_OK;
         HIPCHK(c, hipStreamSynchronize(c->st));
         float ms = 0; (void)hipEventElapsedTime(&ms, a, b); c->collapse_ms = ms;
         kt_resolve(c);
@@ -1125,17 +1143,22 @@ int shard_import(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, u
 // ---- cascade + count vectors
 // do rounds 1 and 2 each walk their own length class (Class::ll) ?
 bool ll_rounds(const mirge_ctx* c, const Class& C) {
-    if (C.KW != 2 || !C.ll_ok || !C.ll_fresh || C.U == 0 || c->n_rounds < 2) return false;
+    if (C.KW != 2 || !C.ll_ok || !C.ll_fresh || c->n_rounds < 2) return false;
     if (const char* e = getenv("MIRGE_LEN_LISTS")) { if (atoi(e) == 0) return false; }       // A/B aid
     const mirge_round &a = c->rounds[0], &b = c->rounds[1];
     return a.len_lt == LL_SPLIT && a.len_gt == 0 && b.len_gt == LL_SPLIT - 1 && b.len_lt == 0;
 }
+// the table's size as the launches see it: with a deferred collapse behind them an upper bound, the real one on the device
+inline uint64_t table_bound(const Class& C) { return C.U + ((C.pending && C.pend_n) ? C.pend_n : 0); }
+inline const unsigned long long* table_dev(const Class& C) { return (C.pending && C.pend_n) ? C.ws_ctr.as<unsigned long long>() : (const unsigned long long*)nullptr; }
 template <int KW, int RN>
 void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, int thr, int r) {
     // round 1 keeps no survivor list (nearly everything survives it), round 2 scans the table and writes the first one;
     // with length-class lists rounds 1 and 2 walk one each (full lanes, and both meet their uniques for the first
     // time: init), and round 3 is the one that scans the table -- 93 % of it is still unannotated by then
     const bool ll = ll_rounds(c, C);
+    const uint64_t UB = table_bound(C);
+    const unsigned long long* U_dev = table_dev(C);
     const uint32_t* list = r <= 1 ? (ll ? C.ll[r].as<uint32_t>() : (const uint32_t*)nullptr)
                                   : (r == 2 && ll ? (const uint32_t*)nullptr : C.act[(r + 1) & 1].as<uint32_t>());
     const unsigned long long* list_n = (r <= 1 && ll) ? C.ll_ctr.as<unsigned long long>() + r : C.act_n + r;
@@ -1147,28 +1170,29 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
         // reads it handed on
         const RoundSch RS = round_schemes(L, P);
         auto kern = RS.n == 0 ? k_probe_round<RN, 0> : (RS.n == 1 ? k_probe_round<RN, 1> : k_probe_round<RN, ROUND_SCHEMES>);
-        hipLaunchKernelGGL(kern, dim3((uint32_t)((C.U + PB - 1) / PB)), dim3(PB), 0, C.st,
-                           C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), C.ann_amb.as<uint8_t>(),
+        hipLaunchKernelGGL(kern, dim3((uint32_t)((UB + PB - 1) / PB)), dim3(PB), 0, C.st,
+                           C.ukeys.as<uint64_t>(), (uint32_t)UB, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), C.ann_amb.as<uint8_t>(),
                            L, P, RS, c->d_stats + (size_t)r * STAT_WORDS, list, list_n, next_list, C.act_n + r + 1,
-                           C.fb.as<uint32_t>(), C.fb_n + r, init);
+                           C.fb.as<uint32_t>(), C.fb_n + r, init, U_dev, (uint32_t)C.U);
         // (a small grid: its blocks stride over the list, whose length -- usually a handful -- only the device knows)
-        hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)std::min<uint64_t>((C.U + MB - 1) / MB, 512)), dim3(MB), 0, C.st,
-                           C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
+        hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)std::min<uint64_t>((UB + MB - 1) / MB, 512)), dim3(MB), 0, C.st,
+                           C.ukeys.as<uint64_t>(), (uint32_t)UB, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
                            C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
-                           (const uint32_t*)C.fb.as<uint32_t>(), (const unsigned long long*)(C.fb_n + r), next_list, C.act_n + r + 1, false);
+                           (const uint32_t*)C.fb.as<uint32_t>(), (const unsigned long long*)(C.fb_n + r), next_list, C.act_n + r + 1, false,
+                           U_dev, (uint32_t)C.U);
         return;
     }
-    hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((C.U + MB - 1) / MB)), dim3(MB), 0, C.st,
-                       C.ukeys.as<uint64_t>(), (uint32_t)C.U, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
+    hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((UB + MB - 1) / MB)), dim3(MB), 0, C.st,
+                       C.ukeys.as<uint64_t>(), (uint32_t)UB, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
                        C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
-                       list, list_n, next_list, C.act_n + r + 1, init);
+                       list, list_n, next_list, C.act_n + r + 1, init, U_dev, (uint32_t)C.U);
 }
 
 // the round number is a template parameter only so that every round is its own kernel symbol in a
 // rocprof trace (the library's own per-round timing and the trace can then be compared)
 template <int KW>
 int annotate_class(mirge_ctx* c, Class& C, int r, const mirge_round& R) {
-    if (C.U == 0) return MIRGE_OK;
+    if (table_bound(C) == 0) return MIRGE_OK;
     RoundDev P{R.lib, R.len_lt, R.len_gt, R.trim5, R.trim3, R.seedlen, R.seedmm, R.maxmm};
     LibDev L = c->libs[R.lib].dev();
     int thr = round_np(P) >= 3 ? c->coop_thr3 : c->coop_thr;
@@ -1199,7 +1223,17 @@ int counts_class(mirge_ctx* c, Class& C, int M) {
         hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(256), lds, C.st, C.coo_g.as<uint32_t>() + sg.start,
                            C.coo_c.as<uint32_t>() + sg.start, (uint32_t)sg.count, sg.sample, c->S, C.ukeys.as<uint64_t>(),
                            C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), M, round_libs, iscan_rounds,
-                           c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu);
+                           c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu, (const unsigned long long*)nullptr);
+    }
+    if (C.pending && C.pend_n) {
+        // the sample of a deferred collapse: its entries follow the settled ones, how many there are the kernel reads itself
+        const size_t lds = M <= CNT_LDS_M ? (size_t)2 * M * 8 : 0;
+        const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (150u << 10) / (lds + 2048)));
+        uint32_t grid = (uint32_t)std::min<uint64_t>(256 * per_cu, ((uint64_t)C.pend_n + 255) / 256);
+        hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(256), lds, C.st, C.coo_g.as<uint32_t>() + C.coo_n,
+                           C.coo_c.as<uint32_t>() + C.coo_n, C.pend_n, C.pend_sample, c->S, C.ukeys.as<uint64_t>(),
+                           C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), M, round_libs, iscan_rounds,
+                           c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu, C.ws_ctr.as<unsigned long long>());
     }
     HIPCHK(c, hipGetLastError());
     return MIRGE_OK;
@@ -1269,7 +1303,7 @@ int annotate(mirge_ctx* c) {
     // ann_round / ann_ref / ann_amb need no fill of their own.
     for (int k = 0; k < 2; ++k) {
         Class& C = c->cls[k];
-        size_t U = std::max<uint64_t>(C.U, 1);
+        size_t U = std::max<uint64_t>(table_bound(C), 1);
         HIPCHK(c, C.ann_round.ensure(U, false, 0, c->st));
         HIPCHK(c, C.ann_ref.ensure(U * 4, false, 0, c->st));
         HIPCHK(c, C.ann_amb.ensure(U, false, 0, c->st));
@@ -1317,6 +1351,13 @@ int annotate(mirge_ctx* c) {
     HIPCHK(c, hipEventRecord(e2, c->st));
     HIPCHK(c, hipMemcpyAsync(c->h_state, c->state.p, w_out * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    if (c->cls[0].pending || c->cls[1].pending) {
+        // a fused call: the collapse was queued in front of all this and is settled only now
+        bool reran = false;
+        int rs = collapse_settle(c, reran);
+        if (rs) return rs;
+        if (reran) return annotate(c);                           // (the cascade ran over the output of an overrun partition pass: once more, over the real table)
+    }
     const unsigned long long* hraw = c->h_state;
     c->h_quant.assign(hraw + w_stats, hraw + w_stats + qn); c->h_iscan.assign(hraw + w_stats + qn, hraw + w_stats + 2 * qn);
     c->h_cat.assign(hraw + w_stats + 2 * qn, hraw + w_stats + 2 * qn + w_cat);
@@ -1460,7 +1501,7 @@ mirge_ctx* mirge_open(const char* species_dir, int32_t n_samples, int32_t device
     if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->st2) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreate(&c->ev_t[0]) != hipSuccess || hipEventCreate(&c->ev_t[1]) != hipSuccess || hipEventCreate(&c->ev_t[2]) != hipSuccess ||
+        hipEventCreate(&c->ev_c[0]) != hipSuccess || hipEventCreate(&c->ev_c[1]) != hipSuccess || hipEventCreate(&c->ev_t[0]) != hipSuccess || hipEventCreate(&c->ev_t[1]) != hipSuccess || hipEventCreate(&c->ev_t[2]) != hipSuccess ||
         hipHostMalloc((void**)&c->h_ctr, 128 + 64) != hipSuccess) {
         fail(nullptr, MIRGE_E_HIP, "cannot create stream / events / pinned buffer"); mirge_close(c); return nullptr;
     }
@@ -1514,6 +1555,7 @@ void mirge_close(mirge_ctx* c) {
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (auto& e : c->ev_t) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_c) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->st2) (void)hipStreamDestroy(c->st2);
@@ -1727,6 +1769,20 @@ int32_t mirge_collapse_ascii_dev(mirge_ctx* c, const void* d_seqs, uint32_t widt
     int rc = mirge_pack_dev(c, d_seqs, width, d_lens, n, c->stage16.p, &n16, c->stage48.p, &n48);
     if (rc) return rc;
     return collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
+}
+
+// collapse + cascade + count vectors of one sample in one call, with nothing waited for in between
+int32_t mirge_collapse_annotate_packed_dev(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, uint64_t n48, int32_t sample) {
+    if (!c || (n16 && !d16) || (n48 && !d48)) return c ? fail(c, MIRGE_E_ARG, "null device pointer") : MIRGE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    static const bool defer = [] { const char* e = getenv("MIRGE_DEFER"); return !(e && atoi(e) == 0); }();      // A/B aid
+    int rc = collapse_packed(c, d16, n16, d48, n48, sample, defer);
+    if (!rc) rc = annotate(c);
+    if (rc && (c->cls[0].pending || c->cls[1].pending)) {        // the cascade could not be queued: settle the collapse alone
+        (void)hipStreamSynchronize(c->st); (void)hipStreamSynchronize(c->st2);
+        bool reran = false; (void)collapse_settle(c, reran);
+    }
+    return rc;
 }
 
 int32_t mirge_validate_keys_dev(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48, uint64_t n48) {

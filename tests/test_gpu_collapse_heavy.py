@@ -86,3 +86,47 @@ def test_partitioned_collapse_equals_table_form(oracle, monkeypatch, c1):
     assert ("collapse_local16" in kt) == bool(c1)          # the overrun case ends in table form
     assert got == want
     assert sum(got.values()) == sum(len(l) for _, l in samples)
+
+
+@pytest.mark.parametrize("c1", [None, "300"])
+def test_fused_collapse_annotate_equals_the_two_calls(monkeypatch, c1):
+    """mirge_collapse_annotate_packed_dev (the cascade queued behind the collapse, the unique count read on the device)
+    against collapse + annotate as two calls: two samples, the partitioned collapse forced onto them; with c1 set its
+    regions overrun, which the fused call learns only after the cascade has run -- it must settle the collapse in table
+    form and run the cascade again by itself."""
+    import numpy as np
+    import torch
+    from mirge_amd import synth
+    from tests import util
+    libs, _ = synth.make_libraries(synth.Profile.small(), 91)
+    samples = [synth.make_reads(libs, 90000, 910 + s, zipf_perm_seed=5 + s) for s in range(2)]
+    monkeypatch.setenv("MIRGE_PART_MIN", "1")
+
+    def run(fused):
+        with capi.Context(None, 2, 0) as ctx:
+            util.load_libs_into(ctx, libs)
+            keep = []
+            for s, (seqs, lens) in enumerate(samples):
+                n = len(lens)
+                d_seqs = torch.from_numpy(seqs).cuda(); d_lens = torch.from_numpy(lens).cuda()
+                k16 = torch.empty((n, 2), dtype=torch.int64, device="cuda"); k48 = torch.empty((n, 6), dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()
+                n16, n48 = ctx.pack_dev(d_seqs.data_ptr(), seqs.shape[1], d_lens.data_ptr(), n, k16.data_ptr(), k48.data_ptr())
+                keep.append((k16, k48))
+                if fused:
+                    ctx.collapse_annotate_packed_dev(k16.data_ptr(), n16, k48.data_ptr(), n48, s)
+                else:
+                    ctx.collapse_packed_dev(k16.data_ptr(), n16, k48.data_ptr(), n48, s)
+            if not fused:
+                ctx.annotate()
+            cv = ctx.counts()
+            return util.gpu_result_dict(ctx), {k: cv[k].copy() for k in cv}, [ctx.round_stats(r + 1)[:2] for r in range(5)], ctx.kernel_times()
+
+    want, wcv, wst, _ = run(False)
+    if c1:
+        monkeypatch.setenv("MIRGE_PART_C1", c1)
+    got, gcv, gst, kt = run(True)
+    assert ("collapse_local16" in kt) == bool(c1)
+    assert got == want and gst == wst
+    for k in wcv:
+        assert np.array_equal(gcv[k], wcv[k]), k

@@ -188,6 +188,14 @@ def test_device_resident_path_and_reset(oracle):
             assert got == util.oracle_result_dict(res)
             for k in ("quant", "iscan", "cat", "tuniq", "lenhist"):
                 assert np.array_equal(cv[k], res[k]), k
+            # same answer from the fused call (the cascade queued behind the collapse, unique count left on the device)
+            ctx.reset()
+            ctx.collapse_annotate_packed_dev(k16.data_ptr(), n16, k48.data_ptr(), n48, 0)
+            assert util.gpu_result_dict(ctx) == got
+            cv2 = ctx.counts()
+            for k in ("quant", "iscan", "cat", "tuniq", "lenhist"):
+                assert np.array_equal(cv2[k], res[k]), k
+            assert [ctx.round_stats(r + 1)[:2] for r in range(5)] == [tuple(int(x) for x in res["stats"][r]) for r in range(5)]
             # same answer from the ASCII-resident entry point
             ctx.reset()
             ctx.collapse_ascii_dev(d_seqs.data_ptr(), seqs.shape[1], d_lens.data_ptr(), n, 0)
