@@ -130,3 +130,41 @@ def test_fused_collapse_annotate_equals_the_two_calls(monkeypatch, c1):
     assert got == want and gst == wst
     for k in wcv:
         assert np.array_equal(gcv[k], wcv[k]), k
+
+
+@pytest.mark.parametrize("part_min", ["1", "1000000000"])
+def test_fused_call_edge_sizes(monkeypatch, part_min):
+    """The fused call on inputs of 0, 1, 2 and 300 reads (empty key streams included), first and second sample, in the
+    partitioned and in the table form: the same table and count vectors as the two calls."""
+    import numpy as np
+    import torch
+    from mirge_amd import synth
+    from tests import util
+    monkeypatch.setenv("MIRGE_PART_MIN", part_min)
+    libs, _ = synth.make_libraries(synth.Profile.tiny(), 93)
+    seqs, lens = synth.make_reads(libs, 300, 931)
+    seqs[7, 3] = ord("N")                                          # one read of the 48-byte class
+    d_seqs = torch.from_numpy(seqs).cuda(); d_lens = torch.from_numpy(lens).cuda()
+    k16 = torch.empty((300, 2), dtype=torch.int64, device="cuda"); k48 = torch.empty((300, 6), dtype=torch.int64, device="cuda")
+    with capi.Context(None, 2, 0) as ctx:
+        util.load_libs_into(ctx, libs)
+        for n0, n1 in ((0, 0), (1, 0), (0, 2), (300, 1), (9, 300)):
+            res = []
+            for fused in (False, True):
+                ctx.reset()
+                for s, n in enumerate((n0, n1)):
+                    torch.cuda.synchronize()
+                    n16, n48 = ctx.pack_dev(d_seqs.data_ptr(), seqs.shape[1], d_lens.data_ptr(), n, k16.data_ptr(), k48.data_ptr()) if n else (0, 0)
+                    a, b = (k16.data_ptr() if n16 else None), (k48.data_ptr() if n48 else None)
+                    if fused:
+                        ctx.collapse_annotate_packed_dev(a, n16, b, n48, s)
+                    else:
+                        ctx.collapse_packed_dev(a, n16, b, n48, s)
+                if not fused:
+                    ctx.annotate()
+                cv = ctx.counts()
+                res.append((util.gpu_result_dict(ctx), {k: cv[k].copy() for k in cv}, [ctx.round_stats(r + 1)[:2] for r in range(5)]))
+            assert res[0][0] == res[1][0] and res[0][2] == res[1][2], (n0, n1)
+            for k in res[0][1]:
+                assert np.array_equal(res[0][1][k], res[1][1][k]), (n0, n1, k)
+            assert sum(sum(v[3]) for v in res[1][0].values()) == n0 + n1
