@@ -382,7 +382,10 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     int kb = (int)std::lround(std::log2((double)std::max<uint64_t>(T, 16)) / 2.0) + 1;   // ~0.25 random entries per bucket
     L.kb = std::min(14, std::max(4, kb));
     L.use_bits = true; L.has_both = false; L.sch.clear(); L.n_slots = L.n_bitw = L.n_pent = 0;
-    if (const char* env = getenv("MIRGE_KB_BIAS")) L.kb = std::min(14, std::max(4, L.kb + atoi(env)));   // tuning aid
+    int kb_max = 14;
+    if (const char* env = getenv("MIRGE_KB_MAX")) kb_max = std::min(15, std::max(4, atoi(env)));         // tuning aid
+    L.kb = std::min(kb_max, std::max(4, kb));
+    if (const char* env = getenv("MIRGE_KB_BIAS")) L.kb = std::min(kb_max, std::max(4, L.kb + atoi(env)));   // tuning aid
     if (const char* env = getenv("MIRGE_KB")) { if (atoi(env) >= 2 && atoi(env) <= 15) L.kb = atoi(env); }   // tests
     uint64_t nb = 1ull << (2 * L.kb);
     {

@@ -38,12 +38,13 @@ def allreduce_flat(flat: np.ndarray, dist=None, device=None) -> np.ndarray:
     return t.cpu().numpy().view(np.uint64)
 
 
-def allreduce_counts(ctx, dist=None, device=None):
+def allreduce_counts(ctx, dist=None, device=None, always=False):
     """The one collective of a sharded run: sum this context's flat count buffer (count vectors, category totals,
     length histogram, trimmed_uniq, per-round readsProcessed / readsAligned) over all ranks and install the sums.
     On GPUs the buffer is packed, reduced (RCCL) and read back from device memory; under gloo (CPU rehearsal) it goes
-    through the host."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    through the host.  A one-rank group has nothing to sum and returns at once, unless `always` (the one-GPU test of
+    the RCCL calls themselves)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not always):
         return
     import torch
     if device is not None and str(device).startswith("cuda") and dist.get_backend() == "nccl":
