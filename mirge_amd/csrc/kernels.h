@@ -85,6 +85,7 @@ struct LibDev {
     const PEnt*     slots;
     const uint32_t* sbits;
     const PEnt*     pent;        // entries of the buckets that hold more than one
+    const uint64_t* ppre;        // pent order: the 32 nt of each entry's context from the lookup position on (pent_pre) -- 8-byte pre-filter of the list drain
     TabDesc   ctab;              // the contiguous table: 4^kb slots
     int32_t   nsch;
     TabDesc   sch[MAX_SCHEMES];  // the block schemes built so far
@@ -727,6 +728,18 @@ k_both_scatter(LibDev L, int k, int B, uint32_t mask, uint32_t* cursor, PEnt* pe
         pent[at] = make_pent(L, p, K, true);
     }
 }
+// 8-byte pre-filter word of an entry: context nt [PCTX_BACK, PCTX_BACK + 32), i.e. what a read lines up against from
+// the nt its lookup started at.  A bucket list is first walked through these (a quarter of the entries' bytes): a
+// candidate whose mismatches inside the word already exceed the round's allowance never has its entry fetched.
+MG_HD uint64_t pent_pre(const PEnt& e) {
+    const uint64_t c1 = (uint64_t)e.c[2] | ((uint64_t)e.c[3] << 32), c2 = (uint64_t)e.c[4] | ((uint64_t)e.c[5] << 32);
+    return (c1 >> (2 * PCTX_BACK - 64)) | (c2 << (128 - 2 * PCTX_BACK));
+}
+__global__ void __launch_bounds__(256)
+k_pent_pre(const PEnt* __restrict__ pent, uint64_t n, uint64_t* __restrict__ ppre) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ppre[i] = pent_pre(pent[i]);
+}
 // slot table of one both-strand index from its CSR form (LibDev::slots)
 __global__ void __launch_bounds__(256)
 k_slot_fill(const uint32_t* __restrict__ off, const PEnt* __restrict__ pent, uint64_t nb, PEnt* __restrict__ slot) {
@@ -1136,6 +1149,18 @@ struct ProbeRead {
 MG_HD void probe_masks(ProbeRead& R) {
     R.ml[0] = ones(2 * R.l) & M55; R.ml[1] = ones(2 * R.l - 64) & M55;
     R.ms[0] = ones(2 * R.s) & M55; R.ms[1] = ones(2 * R.s - 64) & M55;
+}
+// The read from nt ps on (what a pre-filter word is compared with) and the mask of the nt that word covers.
+MG_HD void pre_query(const uint64_t r0, const uint64_t r1, int l, int ps, uint64_t& rr, uint64_t& mask) {
+    const int sh = 2 * ps;
+    rr = sh == 0 ? r0 : (sh < 64 ? (r0 >> sh) | (r1 << (64 - sh)) : r1 >> (sh - 64));
+    const int n = l - ps < 32 ? l - ps : 32;
+    mask = ones(2 * n) & M55;
+}
+// lower bound of the candidate's mismatches: those among the nt the word covers
+MG_HD int pre_mism(uint64_t rr, uint64_t mask, uint64_t pre) {
+    const uint64_t d = rr ^ pre;
+    return popc64((d | (d >> 1)) & mask);
 }
 // NS = schemes of RS looked at (a template parameter of the kernel: rounds without schemes carry none of it)
 template <int NS>
@@ -1822,10 +1847,10 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     // ---- drain: lane = (chunk, entry); every chunk's owner is told through LDS
     auto judge = [&](uint32_t meta, uint32_t at) {
         const uint32_t owner = meta & 255;
-        const PEnt e = load_pent(L.pent, at);
         ProbeRead O;
         O.r[0] = s_r0[owner]; O.r[1] = s_r1[owner];
         O.l = (int)(s_ls[owner] & 255); O.s = (int)((s_ls[owner] >> 8) & 255);
+        const PEnt e = load_pent(L.pent, at);
         probe_masks(O);
         int f, sm, tm; uint32_t w, ref;
         if (probe_verify(P, O, (int)((meta >> 20) & 31), (int)((meta >> 14) & 63), e, f, sm, tm, w, ref)) {
@@ -1841,10 +1866,27 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
             const uint32_t meta = j < qn ? s_q4meta[j] : 0u;
             if ((meta >> 31) && ei <= ((meta >> 8) & 63)) judge(meta, s_q4lo[j] + ei);
         }
-        const uint32_t qm = s_qn64 < (uint32_t)PQ64 ? s_qn64 : (uint32_t)PQ64;
-        for (uint32_t j = tid >> 6; j < qm; j += PB / 64) {
-            const uint32_t meta = s_q64meta[j];
-            if ((meta >> 31) && lane <= ((meta >> 8) & 63)) judge(meta, s_q64lo[j] + lane);
+        // a 64-entry chunk has ONE owner: the wave takes the owner's read into scalar registers (readfirstlane) and
+        // walks the list through its 8-byte pre-filter words first -- a lane's share is one 8-byte load, XOR and a
+        // popcount; the 32-byte entry is fetched only for a candidate the word does not rule out (the drain of the
+        // two-mismatch round was bound by the lines its ~35-entry lists span, not by arithmetic or latency: scalar
+        // owner data alone, and several chunks per step, both measured flat)
+        const uint32_t qm0 = s_qn64 < (uint32_t)PQ64 ? s_qn64 : (uint32_t)PQ64;
+        const uint32_t qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)qm0);
+        for (uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)); j < qm; j += PB / 64) {
+            const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_q64meta[j]);
+            if (!(meta >> 31)) continue;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_q64lo[j]);
+            const uint32_t owner = meta & 255;
+            const uint64_t r0 = s_r0[owner], r1 = s_r1[owner];
+            const uint64_t u0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r0) |
+                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r0 >> 32)) << 32);
+            const uint64_t u1 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r1) |
+                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r1 >> 32)) << 32);
+            const uint32_t ls = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ls[owner]);
+            uint64_t rr, pm;
+            pre_query(u0, u1, (int)(ls & 255), (int)((meta >> 14) & 63), rr, pm);
+            if (lane <= ((meta >> 8) & 63) && pre_mism(rr, pm, L.ppre[lo + lane]) <= P.maxmm) judge(meta, lo + lane);
         }
     }
     __syncthreads();

@@ -97,7 +97,7 @@ struct Lib {
     bool use_bits = true;                // false: koff is small enough to stay in L2, the occupancy bitmap is skipped
     // both-strand slot tables (LibDev::slots ...): the contiguous one is built with the library, the block-scheme ones
     // the first time a cascade holds a round that can use them (ensure_schemes); all in two buffers
-    DevBuf slots, sbits, pent; uint64_t n_slots = 0, n_bitw = 0, n_pent = 0; bool has_both = false;
+    DevBuf slots, sbits, pent, ppre; uint64_t n_slots = 0, n_bitw = 0, n_pent = 0; bool has_both = false;
     TabDesc ctab{0, 0, 0}; std::vector<TabDesc> sch;
     LibDev dev() const {
         LibDev L;
@@ -105,12 +105,12 @@ struct Lib {
         L.kent = kent.as<KEnt>(); L.kpre = kpre.as<uint64_t>(); L.kbits = use_bits ? kbits.as<uint32_t>() : nullptr; L.ref_start = dref.as<uint32_t>();
         L.ref_lut = dlut.as<uint32_t>(); L.lut_shift = lut_shift;
         L.n_refs = (uint32_t)names.size(); L.T = (uint32_t)T; L.kb = kb;
-        L.slots = has_both ? slots.as<PEnt>() : nullptr; L.sbits = sbits.as<uint32_t>(); L.pent = pent.as<PEnt>(); L.ctab = ctab;
+        L.slots = has_both ? slots.as<PEnt>() : nullptr; L.sbits = sbits.as<uint32_t>(); L.pent = pent.as<PEnt>(); L.ppre = ppre.as<uint64_t>(); L.ctab = ctab;
         L.nsch = (int)sch.size();
         for (int j = 0; j < MAX_SCHEMES; ++j) L.sch[j] = j < L.nsch ? sch[j] : TabDesc{0, 0, 0};
         return L;
     }
-    void release() { text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); slots.release(); sbits.release(); pent.release(); sch.clear(); n_slots = n_bitw = n_pent = 0; has_both = false; loaded = false; }
+    void release() { text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); slots.release(); sbits.release(); pent.release(); ppre.release(); sch.clear(); n_slots = n_bitw = n_pent = 0; has_both = false; loaded = false; }
 };
 
 constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
@@ -294,6 +294,7 @@ int build_both(mirge_ctx* c, Lib& L, int k, int B, uint32_t mask) {
     if (base + 2 * T >= 0xFFFFFFF0ull || L.n_slots + nbk >= 0xFFFFFFF0ull || L.n_bitw + nbk / 32 >= (1ull << 27))
         return fail(c, MIRGE_E_LIMIT, "seed tables of a library exceed 2^32 entries");
     HIPCHK(c, L.pent.ensure((base + 2 * T) * sizeof(PEnt), true, base * sizeof(PEnt), c->st));
+    HIPCHK(c, L.ppre.ensure((base + 2 * T) * 8, true, base * 8, c->st));
     HIPCHK(c, L.slots.ensure((L.n_slots + nbk) * sizeof(PEnt), true, L.n_slots * sizeof(PEnt), c->st));
     HIPCHK(c, L.sbits.ensure((L.n_bitw + nbk / 32 + 1) * 4, true, L.n_bitw * 4, c->st));
     HIPCHK(c, c->hist.ensure((nbk + 1) * 4, false, 0, c->st));
@@ -308,6 +309,7 @@ int build_both(mirge_ctx* c, Lib& L, int k, int B, uint32_t mask) {
     HIPCHK(c, hipMemcpyAsync(c->hist.p, c->off_tmp.p, nbk * 4, hipMemcpyDeviceToDevice, c->st));
     hipLaunchKernelGGL(k_both_scatter, dim3(grid), dim3(256), 0, c->st, L.dev(), k, B, mask, c->hist.as<uint32_t>(), L.pent.as<PEnt>());
     hipLaunchKernelGGL(k_slot_fill, dim3((uint32_t)((nbk + 255) / 256)), dim3(256), 0, c->st, c->off_tmp.as<uint32_t>(), L.pent.as<PEnt>(), nbk, L.slots.as<PEnt>() + L.n_slots);
+    hipLaunchKernelGGL(k_pent_pre, dim3((uint32_t)((2 * T + 255) / 256)), dim3(256), 0, c->st, L.pent.as<PEnt>() + base, 2 * T, L.ppre.as<uint64_t>() + base);
     HIPCHK(c, hipGetLastError());
     L.n_pent = base + 2 * T; L.n_slots += nbk; L.n_bitw += nbk / 32;
     return MIRGE_OK;

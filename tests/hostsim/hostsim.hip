@@ -18,7 +18,7 @@ struct SimLib {
     std::vector<PEnt> slots, pent; std::vector<uint32_t> sbits; TabDesc ctab{0, 0, 0}; std::vector<TabDesc> sch;
     LibDev dev() const { LibDev L; L.text = text.data(); L.bad = bad.data(); L.koff = koff.data(); L.kent = kent.data(); L.kpre = kpre.data(); L.kbits = kbits.data();
                          L.ref_start = ref_start.data(); L.ref_lut = lut.data(); L.lut_shift = lut_shift; L.n_refs = (uint32_t)ref_start.size() - 1; L.T = T; L.kb = kb;
-                         L.slots = slots.empty() ? nullptr : slots.data(); L.sbits = sbits.data(); L.pent = pent.data(); L.ctab = ctab;
+                         L.slots = slots.empty() ? nullptr : slots.data(); L.sbits = sbits.data(); L.pent = pent.data(); L.ppre = nullptr; L.ctab = ctab;
                          L.nsch = (int)sch.size();
                          for (int j = 0; j < MAX_SCHEMES; ++j) L.sch[j] = j < L.nsch ? sch[j] : TabDesc{0, 0, 0};
                          return L; }
