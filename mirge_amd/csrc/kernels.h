@@ -1463,6 +1463,16 @@ __host__ __device__ inline void match_long(const uint64_t* __restrict__ rec, int
 // valid alignments are rare next to candidates, so the atomics are off the critical path.  The kernel
 // is instruction-issue bound (rocprof: SQ_ACTIVE_INST_ANY ~ 90 % of SIMD time), so the inner check
 // is kept to one 16-byte load and ~20 VALU instructions.
+// A survivor list as a launch reads / writes it.  Dense (K <= 1): p[0 .. n[0]).  Split (K > 1): K sub-lists, sub-list k =
+// p[k * cap .. k * cap + n[k * LIST_NSTRIDE]) -- block b of the writing launch appends to sub-list b % K, so the K length
+// words take the appends of a launch between them.  Why: every block of a round ends with ONE returning atomic on the
+// list's length, and the device serves atomics on one address one after the other, ~12 ns each (they execute at the
+// memory side, past the eight L2s): 43 K blocks of round 3 on one word are a 0.53 ms chain, whatever else the kernel does
+// (profiles/r02/v4_phase_elimination.txt).  The reading launch maps block b to tile b / K of sub-list b % K, which
+// costs it nothing; cap = (blocks of the writing launch that share a sub-list) x block size, so a sub-list cannot overrun.
+constexpr int LIST_K = 64, LIST_NSTRIDE = 16;    // sub-lists of a split list; 64-bit words between their length words (128 B)
+struct ListIn  { const uint32_t* p; const unsigned long long* n; uint32_t K, cap; };      // p == null: the whole table
+struct ListOut { uint32_t* p; unsigned long long* n; uint32_t K, cap; };                  // p == null: no list is kept
 constexpr int MB = 256;
 #ifndef MG_QCAP
 #define MG_QCAP 384
@@ -1700,16 +1710,36 @@ template <int KW, int RN>
 __global__ void __launch_bounds__(MB, MG_MATCH_WAVES)
 k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref,
               uint8_t* ann_amb, LibDev L, RoundDev P, int thr, unsigned long long* stats,
-              const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_n,
+              ListIn in, const uint32_t* __restrict__ list2, const unsigned long long* __restrict__ list2_n,
               uint32_t* next_list, unsigned long long* next_n, bool init,
               const unsigned long long* __restrict__ U_dev, uint32_t U0) {
     // U_dev (nullable): the table's size is still on the device -- U0 uniques + the new ones of a collapse whose packed
     // rank counter (new uniques in its high half) the host has not read yet; U is then an upper bound (grid sizing)
+    // in: the launch's work (dense, split, or the whole table); list2 (nullable): a second, dense list behind it (what
+    // earlier launches of this kernel left of the reads the probe kernel had handed them).  Survivors go to ONE dense list.
     if (U_dev) U = U0 + (uint32_t)(*U_dev >> 32);
-    const uint32_t n = (list && list_n) ? (uint32_t)*list_n : U;          // (a list without a length word is as long as the table: EMPTY = a hole)
-    for (uint32_t bid = blockIdx.x; (uint64_t)bid * MB < n; bid += gridDim.x) {
-        match_block<KW, RN>(bid, n, ukeys, ann_round, ann_ref, ann_amb, L, P, thr, stats, list, next_list, next_n, init);
-        __syncthreads();                                   // the block's LDS state is reused by its next piece of work
+    if (in.K > 1) {
+        const uint32_t per = in.cap / MB;                  // tiles a sub-list can hold (cap is a multiple of the block size)
+        for (uint32_t t = blockIdx.x; t < in.K * per; t += gridDim.x) {
+            const uint32_t k = t % in.K, j = t / in.K;
+            const uint32_t nk = (uint32_t)in.n[(size_t)k * LIST_NSTRIDE];
+            if ((uint64_t)j * MB >= nk) continue;
+            match_block<KW, RN>(j, nk, ukeys, ann_round, ann_ref, ann_amb, L, P, thr, stats, in.p + (size_t)k * in.cap, next_list, next_n, init);
+            __syncthreads();                               // the block's LDS state is reused by its next piece of work
+        }
+    } else {
+        const uint32_t n = (in.p && in.n) ? (uint32_t)*in.n : U;          // (a list without a length word is as long as the table: EMPTY = a hole)
+        for (uint32_t bid = blockIdx.x; (uint64_t)bid * MB < n; bid += gridDim.x) {
+            match_block<KW, RN>(bid, n, ukeys, ann_round, ann_ref, ann_amb, L, P, thr, stats, in.p, next_list, next_n, init);
+            __syncthreads();
+        }
+    }
+    if (list2) {
+        const uint32_t n2 = (uint32_t)*list2_n;
+        for (uint32_t bid = blockIdx.x; (uint64_t)bid * MB < n2; bid += gridDim.x) {
+            match_block<KW, RN>(bid, n2, ukeys, ann_round, ann_ref, ann_amb, L, P, thr, stats, list2, next_list, next_n, false);
+            __syncthreads();
+        }
     }
 }
 
@@ -1732,16 +1762,18 @@ template <int NS> struct ProbeQ { static constexpr int Q4 = NS >= 3 ? 768 : 320,
 #ifndef MG_PROBE_WAVES
 #define MG_PROBE_WAVES 6
 #endif
+#ifndef MG_PROBE_WAVES0
+#define MG_PROBE_WAVES0 8                       // the scheme-free instantiation (rounds 1 and 4 of the reference cascade) fits 64 registers but for 16 B of scratch
+#endif
 // chunk: lo = first entry; meta = owner (0-7) | entries - 1 (8-13) | ps (14-19) | K (20-24) | written (31)
 MG_HD uint32_t chunk_meta(uint32_t owner, uint32_t cnt, int ps, int K) {
     return owner | ((cnt - 1) << 8) | ((uint32_t)ps << 14) | ((uint32_t)K << 20) | 0x80000000u;
 }
 template <int RN, int NS>
-__global__ void __launch_bounds__(PB, MG_PROBE_WAVES)
+__global__ void __launch_bounds__(PB, NS == 0 ? MG_PROBE_WAVES0 : MG_PROBE_WAVES)
 k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb,
               LibDev L, RoundDev P, RoundSch RS, unsigned long long* stats,
-              const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_n,
-              uint32_t* next_list, unsigned long long* next_n, uint32_t* fb_list, unsigned long long* fb_n, bool init,
+              ListIn in, ListOut out, uint32_t* fb_list, unsigned long long* fb_n, bool init,
               const unsigned long long* __restrict__ U_dev, uint32_t U0) {
     constexpr int PQ4 = ProbeQ<NS>::Q4, PQ64 = ProbeQ<NS>::Q64;
     if (U_dev) U = U0 + (uint32_t)(*U_dev >> 32);               // as in k_match_round
@@ -1751,9 +1783,24 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     __shared__ uint32_t s_q4lo[PQ4], s_q4meta[PQ4], s_q64lo[PQ64], s_q64meta[PQ64];
     __shared__ uint32_t s_qn4, s_qn64, s_wcnt[2][PB / 64], s_base[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t n = (list && list_n) ? (uint32_t)*list_n : U;
-    if (blockIdx.x * PB >= n) return;
-    const uint32_t i = blockIdx.x * PB + tid;
+    // this block's tile of the work: tile blockIdx.x of a dense list (or of the table), tile b / K of sub-list b % K of a split one
+    const uint32_t* __restrict__ list = in.p;
+    uint32_t n, i0;
+    if (in.K > 1) {
+        const uint32_t sk = blockIdx.x % in.K;
+        n = (uint32_t)in.n[(size_t)sk * LIST_NSTRIDE]; i0 = (blockIdx.x / in.K) * PB; list += (size_t)sk * in.cap;
+    } else {
+        n = (list && in.n) ? (uint32_t)*in.n : U; i0 = blockIdx.x * PB;
+    }
+    if (i0 >= n) return;
+    uint32_t* next_list = out.p;
+    unsigned long long* next_n = out.n;
+    uint32_t next_cap = 0xFFFFFFFFu;
+    if (out.K > 1) {
+        const uint32_t ok = blockIdx.x % out.K;
+        next_list += (size_t)ok * out.cap; next_n += (size_t)ok * LIST_NSTRIDE; next_cap = out.cap;
+    }
+    const uint32_t i = i0 + tid;
     const uint32_t u = i < n ? (list ? list[i] : i) : EMPTY;
     uint64_t k[2] = {0, 0};
     uint8_t done_before = 0;
@@ -1924,7 +1971,10 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1;
-    if (surv) next_list[s_base[0] + s_wcnt[0][tid >> 6] + (uint32_t)__popcll(sv & below)] = u;
+    if (surv) {
+        const uint32_t at = s_base[0] + s_wcnt[0][tid >> 6] + (uint32_t)__popcll(sv & below);
+        if (at < next_cap) next_list[at] = u;               // (cannot fail: cap = the blocks that share the sub-list x PB)
+    }
     if (fb) fb_list[s_base[1] + s_wcnt[1][tid >> 6] + (uint32_t)__popcll(fv & below)] = u;
 }
 

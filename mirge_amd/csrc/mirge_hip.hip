@@ -130,6 +130,10 @@ struct Class {
     DevBuf act[2];                              // ping-pong lists of still-unannotated uniques
     unsigned long long* act_n = nullptr;        // their lengths (device; lives in the context's state arena)
     DevBuf fb; unsigned long long* fb_n = nullptr;      // reads the probe kernel hands to the generic kernel, per round (16-byte class)
+    // what the generic kernel's launches over `fb` leave unannotated: ping-pong dense lists of their own, read by the next
+    // round's launch of that kernel (the probe kernel's survivors go to split lists: kernels.h, ListOut)
+    DevBuf fbs[2]; unsigned long long* fbs_n = nullptr;
+    struct ListFmt { uint32_t K = 0, cap = 0; } lf[MIRGE_MAX_ROUNDS + 1];      // layout of the list round r reads (K <= 1: dense)
     // The two classes run side by side (the 48-byte class is tiny: its kernels are latency-, not throughput-bound):
     // each has its own stream and its own collapse workspaces.
     hipStream_t st = nullptr;
@@ -144,7 +148,7 @@ struct Class {
     DevBuf ll[2], ll_ctr; bool ll_ok = true, ll_fresh = false;
     std::vector<Segment> segs;
     void reset() { U = 0; coo_n = 0; gvalid = false; segs.clear(); ll_ok = true; ll_fresh = false; }
-    void release() { ukeys.release(); coo_g.release(); coo_c.release(); gslots.release(); act[0].release(); act[1].release(); fb.release(); ann_round.release(); ann_ref.release(); ann_amb.release();
+    void release() { ukeys.release(); coo_g.release(); coo_c.release(); gslots.release(); act[0].release(); act[1].release(); fb.release(); fbs[0].release(); fbs[1].release(); ann_round.release(); ann_ref.release(); ann_amb.release();
                      ws_lslots.release(); ws_cnt.release(); ws_cnt0.release(); ws_ctr.release();
                      pt_k1.release(); pt_w1.release(); pt_k2.release(); pt_w2.release(); pt_cur.release(); ll[0].release(); ll[1].release(); ll_ctr.release(); }
 };
@@ -1164,33 +1168,46 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
     const bool ll = ll_rounds(c, C);
     const uint64_t UB = table_bound(C);
     const unsigned long long* U_dev = table_dev(C);
-    const uint32_t* list = r <= 1 ? (ll ? C.ll[r].as<uint32_t>() : (const uint32_t*)nullptr)
-                                  : (r == 2 && ll ? (const uint32_t*)nullptr : C.act[(r + 1) & 1].as<uint32_t>());
-    const unsigned long long* list_n = (r <= 1 && ll) ? C.ll_ctr.as<unsigned long long>() + r : C.act_n + r;
-    const bool writes = ll ? r >= 2 : r >= 1;
-    uint32_t* next_list = (writes && r + 1 < c->n_rounds) ? C.act[r & 1].as<uint32_t>() : (uint32_t*)nullptr;
+    unsigned long long* const cnt_in = C.act_n + (size_t)r * LIST_K * LIST_NSTRIDE;
+    unsigned long long* const cnt_out = C.act_n + (size_t)(r + 1) * LIST_K * LIST_NSTRIDE;
+    ListIn in{nullptr, nullptr, 0, 0};
+    if (r <= 1) { if (ll) in = ListIn{C.ll[r].as<uint32_t>(), C.ll_ctr.as<unsigned long long>() + r, 1, 0}; }
+    else if (!(r == 2 && ll)) in = ListIn{C.act[(r + 1) & 1].as<uint32_t>(), cnt_in, C.lf[r].K, C.lf[r].cap};
+    const bool writes = (ll ? r >= 2 : r >= 1) && r + 1 < c->n_rounds;
     const bool init = r == 0 || (r == 1 && ll);
+    // the lists of the generic kernel's own leftovers (16-byte class, probe rounds): read whenever an earlier round wrote any
+    const bool had_list = ll ? r >= 3 : r >= 2;
+    const uint32_t* fbs_in = (KW == 2 && had_list) ? C.fbs[(r + 1) & 1].as<uint32_t>() : (const uint32_t*)nullptr;
     if (KW == 2 && probe_round(L, P)) {
         // the probe path (kernels.h: k_probe_round) for what the slot tables can serve, then the generic kernel over the
         // reads it handed on
         const RoundSch RS = round_schemes(L, P);
         auto kern = RS.n == 0 ? k_probe_round<RN, 0> : (RS.n == 1 ? k_probe_round<RN, 1> : k_probe_round<RN, ROUND_SCHEMES>);
-        hipLaunchKernelGGL(kern, dim3((uint32_t)((UB + PB - 1) / PB)), dim3(PB), 0, C.st,
+        const uint32_t grid = in.K > 1 ? in.K * (in.cap / PB) : (uint32_t)((UB + PB - 1) / PB);
+        const uint32_t cap_out = (grid + LIST_K - 1) / LIST_K * PB;          // blocks that share a sub-list x what each can append
+        ListOut out{nullptr, nullptr, 0, 0};
+        if (writes) { out = ListOut{C.act[r & 1].as<uint32_t>(), cnt_out, (uint32_t)LIST_K, cap_out}; C.lf[r + 1].K = LIST_K; C.lf[r + 1].cap = cap_out; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(PB), 0, C.st,
                            C.ukeys.as<uint64_t>(), (uint32_t)UB, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), C.ann_amb.as<uint8_t>(),
-                           L, P, RS, c->d_stats + (size_t)r * STAT_WORDS, list, list_n, next_list, C.act_n + r + 1,
+                           L, P, RS, c->d_stats + (size_t)r * STAT_WORDS, in, out,
                            C.fb.as<uint32_t>(), C.fb_n + r, init, U_dev, (uint32_t)C.U);
-        // (a small grid: its blocks stride over the list, whose length -- usually a handful -- only the device knows)
+        // (a small grid: its blocks stride over the lists, whose lengths -- usually a handful -- only the device knows)
         hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)std::min<uint64_t>((UB + MB - 1) / MB, 512)), dim3(MB), 0, C.st,
                            C.ukeys.as<uint64_t>(), (uint32_t)UB, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
                            C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
-                           (const uint32_t*)C.fb.as<uint32_t>(), (const unsigned long long*)(C.fb_n + r), next_list, C.act_n + r + 1, false,
+                           ListIn{C.fb.as<uint32_t>(), C.fb_n + r, 1, 0}, fbs_in, (const unsigned long long*)(C.fbs_n + r),
+                           writes ? C.fbs[r & 1].as<uint32_t>() : (uint32_t*)nullptr, C.fbs_n + r + 1, false,
                            U_dev, (uint32_t)C.U);
         return;
     }
+    // the generic kernel as the round's matcher: it reads whatever layout the previous round left (and the leftovers'
+    // list), and writes one dense list
+    if (writes) { C.lf[r + 1].K = 1; C.lf[r + 1].cap = 0; }
     hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((UB + MB - 1) / MB)), dim3(MB), 0, C.st,
                        C.ukeys.as<uint64_t>(), (uint32_t)UB, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
                        C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
-                       list, list_n, next_list, C.act_n + r + 1, init, U_dev, (uint32_t)C.U);
+                       in, fbs_in, (const unsigned long long*)(C.fbs_n + r),
+                       writes ? C.act[r & 1].as<uint32_t>() : (uint32_t*)nullptr, cnt_out, init, U_dev, (uint32_t)C.U);
 }
 
 // the round number is a template parameter only so that every round is its own kernel symbol in a
@@ -1312,14 +1329,20 @@ int annotate(mirge_ctx* c) {
         HIPCHK(c, C.ann_round.ensure(U, false, 0, c->st));
         HIPCHK(c, C.ann_ref.ensure(U * 4, false, 0, c->st));
         HIPCHK(c, C.ann_amb.ensure(U, false, 0, c->st));
-        HIPCHK(c, C.act[0].ensure(U * 4, false, 0, c->st));
-        HIPCHK(c, C.act[1].ensure(U * 4, false, 0, c->st));
-        if (k == 0) HIPCHK(c, C.fb.ensure(U * 4, false, 0, c->st));
+        HIPCHK(c, C.act[0].ensure((U + (size_t)LIST_K * PB) * 4, false, 0, c->st));      // (a split list: LIST_K sub-lists, each rounded up to whole blocks)
+        HIPCHK(c, C.act[1].ensure((U + (size_t)LIST_K * PB) * 4, false, 0, c->st));
+        if (k == 0) {
+            HIPCHK(c, C.fb.ensure(U * 4, false, 0, c->st));
+            HIPCHK(c, C.fbs[0].ensure(U * 4, false, 0, c->st));
+            HIPCHK(c, C.fbs[1].ensure(U * 4, false, 0, c->st));
+        }
+        for (auto& f : C.lf) f = Class::ListFmt{};
     }
     int M = (int)c->libs[MIRGE_LIB_MIRNA].names.size(), S = c->S;
     size_t qn = std::max<size_t>((size_t)M * S, 1);
     const size_t w_stats = MIRGE_MAX_ROUNDS * STAT_WORDS, w_cat = (size_t)5 * S, w_len = (size_t)LEN_BINS * S, w_tu = (size_t)S;
-    const size_t w_out = w_stats + 2 * qn + w_cat + w_len + w_tu, w_all = w_out + 2 * (MIRGE_MAX_ROUNDS + 1) + MIRGE_MAX_ROUNDS;
+    const size_t w_act = (size_t)(MIRGE_MAX_ROUNDS + 1) * LIST_K * LIST_NSTRIDE;        // list length words of one key class: LIST_K per round, 128 B apart
+    const size_t w_out = w_stats + 2 * qn + w_cat + w_len + w_tu, w_all = w_out + 2 * w_act + MIRGE_MAX_ROUNDS + (MIRGE_MAX_ROUNDS + 1);
     HIPCHK(c, c->state.ensure(w_all * 8, false, 0, c->st));
     if (c->h_state_cap < w_out) {
         if (c->h_state) (void)hipHostFree(c->h_state);
@@ -1330,8 +1353,9 @@ int annotate(mirge_ctx* c) {
     c->d_stats = c->state.as<unsigned long long>();
     c->d_quant = c->d_stats + w_stats; c->d_iscan = c->d_quant + qn; c->d_cat = c->d_iscan + qn;
     c->d_len = c->d_cat + w_cat; c->d_tu = c->d_len + w_len;
-    c->cls[0].act_n = c->d_tu + w_tu; c->cls[1].act_n = c->cls[0].act_n + (MIRGE_MAX_ROUNDS + 1);
-    c->cls[0].fb_n = c->cls[1].act_n + (MIRGE_MAX_ROUNDS + 1);
+    c->cls[0].act_n = c->d_tu + w_tu; c->cls[1].act_n = c->cls[0].act_n + w_act;
+    c->cls[0].fb_n = c->cls[1].act_n + w_act;
+    c->cls[0].fbs_n = c->cls[0].fb_n + MIRGE_MAX_ROUNDS; c->cls[1].fbs_n = c->cls[0].fbs_n;       // (the 48-byte class has no such lists: its launches get none)
     HIPCHK(c, hipMemsetAsync(c->state.p, 0, w_all * 8, c->st));
     hipEvent_t e0 = c->ev_t[0], e1 = c->ev_t[1], e2 = c->ev_t[2];
     HIPCHK(c, hipEventRecord(e0, c->st));

@@ -60,3 +60,40 @@ def test_random_cascades_through_slot_tables(oracle, monkeypatch, seed, kb):
         assert np.array_equal(cv[k], res[k]), (k, rounds)
     assert stats == [(int(a), int(b)) for a, b in res["stats"]][:len(rounds)], rounds
     assert sum(b for _, b in stats) > 1000
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_cascades_that_mix_probe_and_generic_rounds(oracle, monkeypatch, seed):
+    """Libraries with and without slot tables in one cascade: a probe round leaves split survivor lists (kernels.h:
+    ListOut) and a list of the generic kernel's leftovers, a round whose library has no slot tables reads both with the
+    generic kernel and leaves one dense list, which the next probe round reads -- every hand-over between the two list
+    layouts, against the oracle."""
+    import math
+    libs, _ = synth.make_libraries(synth.Profile.small(), 800 + seed)
+    kbs = {name: min(14, max(4, int(round(math.log2(max(len(l.text) + l.n, 16)) / 2.0)) + 1)) for name, l in libs.items()}
+    cut = sorted(kbs.values())[2]                            # the two largest libraries get slot tables, the others none
+    assert min(kbs.values()) < cut <= max(kbs.values()), kbs
+    monkeypatch.setenv("MIRGE_SLOTS_MIN_KB", str(cut))
+    rng = np.random.default_rng(3000 + seed)
+    samples = [synth.make_reads(libs, 30000, 810 + seed)]
+    seqs, lens = samples[0]
+    for i in rng.integers(0, len(lens), size=300):
+        seqs[i, int(rng.integers(0, lens[i]))] = ord("N")
+    for i in rng.integers(0, len(lens), size=300):           # reads below a k-mer: handed from the probe to the generic kernel
+        lens[i] = int(rng.integers(4, 16))
+    order = list(rng.permutation(4)) + list(rng.permutation(4))
+    rounds = [(int(lib), 0, 0, int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.choice([12, 16, 20, 28])),
+               int(rng.integers(0, 3)), int(rng.integers(0, 3))) for lib in order[:int(rng.integers(5, 9))]]
+    with capi.Context(None, 1, 0) as ctx:
+        util.load_libs_into(ctx, libs)
+        ctx.set_rounds(rounds)
+        ctx.collapse_seqs(seqs, 0, lens)
+        ctx.annotate()
+        got = util.gpu_result_dict(ctx)
+        cv = ctx.counts()
+        stats = [ctx.round_stats(r + 1)[:2] for r in range(len(rounds))]
+    res = oracle.run_path(util.oracle_libs(libs, oracle), samples, rounds=rounds, use_index=True, nthreads=8, maxlen=capi.MAX_READ_LEN)
+    assert got == util.oracle_result_dict(res), rounds
+    for k in ("quant", "iscan", "cat", "tuniq", "lenhist"):
+        assert np.array_equal(cv[k], res[k]), (k, rounds)
+    assert stats == [(int(a), int(b)) for a, b in res["stats"]][:len(rounds)], rounds
