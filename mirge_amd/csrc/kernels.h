@@ -461,7 +461,7 @@ k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
     __shared__ uint64_t tk[PT_C2 * 2];
     __shared__ uint32_t towner[2 * PT_C2];
     __shared__ uint32_t tcnt[PT_C2];
-    __shared__ uint32_t s_scan[PT_BLOCK];
+    __shared__ uint32_t s_scan[PT_BLOCK / 64];
     __shared__ uint32_t s_base[2];
     constexpr int PER = PT_C2 / PT_BLOCK;
     const uint32_t tid = threadIdx.x, q = blockIdx.x;
@@ -528,15 +528,22 @@ k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
         }
         if (!rep) trep[e] = EMPTY;                              // from here on: EMPTY = not a representative
     }
-    s_scan[tid] = nrep | (nnew << 16);
-    __syncthreads();
-    for (int o = 1; o < PT_BLOCK; o <<= 1) {
-        const uint32_t t = (int)tid >= o ? s_scan[tid - o] : 0u;
-        __syncthreads();
-        s_scan[tid] += t;
-        __syncthreads();
+    // inclusive scan of (representatives | new uniques << 16) over the block: inside each wave by shuffles, across the
+    // 16 waves through their totals in LDS -- two barriers (a 10-step scan in LDS cost twenty)
+    uint32_t incl = nrep | (nnew << 16);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if ((int)(tid & 63) >= o) incl += t;
     }
-    const uint32_t incl = s_scan[tid];
+    if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
+    __syncthreads();
+    {
+        uint32_t before = 0;
+#pragma unroll
+        for (int w = 0; w < PT_BLOCK / 64; ++w) before += w < (int)(tid >> 6) ? s_scan[w] : 0u;
+        incl += before;
+    }
     if (tid == PT_BLOCK - 1) {
         const uint32_t trp = incl & 0xFFFF, tnw = incl >> 16;
         const unsigned long long old = atomicAdd(&ctr[0], ((unsigned long long)tnw << 32) | trp);
