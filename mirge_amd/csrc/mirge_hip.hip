@@ -181,6 +181,7 @@ struct KTime { const char* name; hipEvent_t a = nullptr, b = nullptr; bool used 
 
 struct mirge_ctx {
     int device = 0;
+    int n_cu = 256;                             // compute units of the device (grid sizes of the striding kernels)
     int S = 1;
     hipStream_t st = nullptr, st2 = nullptr;        // st: everything; st2: the 48-byte key class inside collapse_packed / annotate
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -488,6 +489,13 @@ bool part_wanted(uint64_t n) {
 }
 // fan-out of the first pass: final partitions (P1 x PT_P2 of them, PT_C2 records each at most) should come out about
 // 40 % full when every read is distinct
+// blocks of a split-pass launch: one per tile.  (MIRGE_PART_GRID = N: tuning aid, N blocks that stride over the tiles
+// with the next tile on its way into registers -- measured 0.52 ms for both passes at two blocks per CU against 0.47:
+// blocks that come and go overlap better than resident ones that prefetch.)
+inline uint32_t part_grid() {
+    if (const char* e = getenv("MIRGE_PART_GRID")) { const long v = atol(e); if (v > 0) return (uint32_t)v; }
+    return 0xFFFFFFFFu;
+}
 int part_p1(uint64_t n) { int p1 = 64; while (p1 < 512 && n > (uint64_t)p1 * 344000ull) p1 *= 2; return p1; }
 template <int KW>
 int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64, int sample, const char* tagA, const char* tagB,
@@ -536,9 +544,11 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
         unsigned long long* ovf = cur + ncur - 1;
         kt_begin(c, "collapse_part16", st);
         auto pass1 = PT_P1 == 64 ? k_part_pass<64> : PT_P1 == 128 ? k_part_pass<128> : PT_P1 == 256 ? k_part_pass<256> : k_part_pass<512>;
-        hipLaunchKernelGGL(pass1, dim3((n + PT_TILE - 1) / PT_TILE, 1), dim3(PT_BLOCK), 0, st, d_keys, d_wt,
+        const uint32_t g1 = std::min<uint32_t>((n + PT_TILE - 1) / PT_TILE, part_grid());
+        const uint32_t g2 = std::min<uint32_t>((C1 + PT_TILE - 1) / PT_TILE, std::max<uint32_t>(1, part_grid() / PT_P1));
+        hipLaunchKernelGGL(pass1, dim3(g1, 1), dim3(PT_BLOCK), 0, st, d_keys, d_wt,
                            (const unsigned long long*)nullptr, n, 0u, pt_shift1(PT_P1), C.pt_k1.as<uint64_t>(), C.pt_w1.as<uint32_t>(), cur, C1, ovf);
-        hipLaunchKernelGGL((k_part_pass<PT_P2>), dim3((C1 + PT_TILE - 1) / PT_TILE, PT_P1), dim3(PT_BLOCK), 0, st, C.pt_k1.as<uint64_t>(),
+        hipLaunchKernelGGL((k_part_pass<PT_P2>), dim3(g2, PT_P1), dim3(PT_BLOCK), 0, st, C.pt_k1.as<uint64_t>(),
                            C.pt_w1.as<uint32_t>(), (const unsigned long long*)cur, C1, C1, pt_shift2(PT_P1), C.pt_k2.as<uint64_t>(), C.pt_w2.as<uint32_t>(),
                            cur + PT_P1, (uint32_t)PT_C2, ovf);
         kt_end(c, "collapse_part16", (uint64_t)n * 16, st);
@@ -1526,6 +1536,7 @@ mirge_ctx* mirge_open(const char* species_dir, int32_t n_samples, int32_t device
     }
     mirge_ctx* c = new mirge_ctx();
     c->device = device; c->S = n_samples;
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) c->n_cu = cu; }
     c->cls[0].KW = 2; c->cls[1].KW = 6;
     if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->st2) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
