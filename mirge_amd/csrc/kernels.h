@@ -494,6 +494,9 @@ k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
     if (nvalid == 0) return;
     const uint64_t* kin = keys_in + (uint64_t)q * PT_C2 * 2;
     const uint32_t* win = wt_in + (uint64_t)q * PT_C2;
+    uint32_t wcur[PER];                                          // the records' counts, fetched with the keys (as in k_part_pass)
+#pragma unroll
+    for (int e = 0; e < PER; ++e) { const uint32_t idx = tid + e * PT_BLOCK; wcur[e] = idx < nvalid ? win[idx] : 0u; }
     for (uint32_t j = tid; j < nvalid * 2; j += PT_BLOCK) tk[j] = kin[j];
     for (uint32_t j = tid; j < 2u * PT_C2; j += PT_BLOCK) towner[j] = EMPTY;
     for (uint32_t j = tid; j < (uint32_t)PT_C2; j += PT_BLOCK) tcnt[j] = 0;
@@ -513,7 +516,7 @@ k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
                 if (tk[o * 2] == k[0] && tk[o * 2 + 1] == k[1]) { trep[e] = o; break; }
                 h = (h + 1) & (2u * PT_C2 - 1);
             }
-            atomicAdd(&tcnt[trep[e]], win[idx]);
+            atomicAdd(&tcnt[trep[e]], wcur[e]);
         }
     }
     __syncthreads();
