@@ -487,8 +487,6 @@ bool part_wanted(uint64_t n) {
     if (const char* e = getenv("MIRGE_PART_MAX")) hi = strtoull(e, nullptr, 10);
     return n >= lo && n <= hi;
 }
-// fan-out of the first pass: final partitions (P1 x PT_P2 of them, PT_C2 records each at most) should come out about
-// 40 % full when every read is distinct
 // blocks of a split-pass launch: one per tile.  (MIRGE_PART_GRID = N: tuning aid, N blocks that stride over the tiles
 // with the next tile on its way into registers -- measured 0.52 ms for both passes at two blocks per CU against 0.47:
 // blocks that come and go overlap better than resident ones that prefetch.)
@@ -496,7 +494,11 @@ inline uint32_t part_grid() {
     if (const char* e = getenv("MIRGE_PART_GRID")) { const long v = atol(e); if (v > 0) return (uint32_t)v; }
     return 0xFFFFFFFFu;
 }
-int part_p1(uint64_t n) { int p1 = 64; while (p1 < 512 && n > (uint64_t)p1 * 344000ull) p1 *= 2; return p1; }
+// fan-out of the first pass: the fewest final partitions (P1 x PT_P2 of them, PT_C2 records each at most) that come out
+// at most ~75 % full when every read is distinct (hashed keys: 2048 is then 13 sigma above the mean).  Fewest, because
+// every partition ends in one atomic on the table's rank counter and those are served one after the other (~12 ns):
+// at 100M reads the fold kernel took 1.68 ms with 131 K partitions -- exactly that chain.
+int part_p1(uint64_t n) { int p1 = 16; while (p1 < 512 && n > (uint64_t)p1 * 400000ull) p1 *= 2; return p1; }
 template <int KW>
 int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64, int sample, const char* tagA, const char* tagB,
                     const uint32_t* d_wt = nullptr, bool allow_part = true) {
@@ -543,7 +545,7 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
         unsigned long long* cur = C.pt_cur.as<unsigned long long>();
         unsigned long long* ovf = cur + ncur - 1;
         kt_begin(c, "collapse_part16", st);
-        auto pass1 = PT_P1 == 64 ? k_part_pass<64> : PT_P1 == 128 ? k_part_pass<128> : PT_P1 == 256 ? k_part_pass<256> : k_part_pass<512>;
+        auto pass1 = PT_P1 == 16 ? k_part_pass<16> : PT_P1 == 32 ? k_part_pass<32> : PT_P1 == 64 ? k_part_pass<64> : PT_P1 == 128 ? k_part_pass<128> : PT_P1 == 256 ? k_part_pass<256> : k_part_pass<512>;
         const uint32_t g1 = std::min<uint32_t>((n + PT_TILE - 1) / PT_TILE, part_grid());
         const uint32_t g2 = std::min<uint32_t>((C1 + PT_TILE - 1) / PT_TILE, std::max<uint32_t>(1, part_grid() / PT_P1));
         hipLaunchKernelGGL(pass1, dim3(g1, 1), dim3(PT_BLOCK), 0, st, d_keys, d_wt,
