@@ -350,7 +350,7 @@ k_validate_keys(const uint64_t* __restrict__ keys, uint64_t n, unsigned long lon
 // ------------------------------------------------------------------------------------------
 // Partitioned collapse (16-byte keys; BASELINE.json's "LDS-staged" collapse in hash form).  The table form above pays
 // one device-scope compare-and-swap and ~3 random lines per distinct key; at the bench's U/N = 0.55 that is what its
-// 0.9 ms are made of.  Here the reads are split by hash bits in two streaming passes of small fan-out (64, then 256)
+// 0.9 ms are made of.  Here the reads are split by hash bits in two streaming passes of small fan-out (16 .. 512 by input size, then 256)
 // into partitions that fit the LDS, and each partition is folded by one workgroup:
 //   k_part_pass : a tile of 2048 records -> duplicates folded in an LDS table (one record per tile and sequence: the
 //                 heavy hitters of miRNA-seq never reach the next pass more than once per tile) -> the tile's distinct
@@ -369,7 +369,7 @@ k_validate_keys(const uint64_t* __restrict__ keys, uint64_t n, unsigned long lon
 #define MG_PT_C2 2048
 #endif
 constexpr int PT_TILE = MG_PT_TILE, PT_BLOCK = 1024;
-constexpr int PT_P2 = MG_PT_P2;                  // fan-out of pass 2 (pass 1: 64 .. 512, by input size)
+constexpr int PT_P2 = MG_PT_P2;                  // fan-out of pass 2 (pass 1: 16 .. 512, by input size)
 constexpr int PT_C2 = MG_PT_C2;                  // records a final partition may hold
 constexpr int pt_log2(int x) { return x <= 1 ? 0 : 1 + pt_log2(x / 2); }
 // hash bits: pass 1 takes the top log2(P1) bits, pass 2 the log2(P2) below them (far above what the LDS tables use)
