@@ -1795,7 +1795,10 @@ constexpr int PB = 256;                          // threads per block
 // the others hardly use them
 template <int NS> struct ProbeQ { static constexpr int Q4 = NS >= 3 ? 768 : 320, Q64 = NS >= 3 ? 256 : 32; };
 #ifndef MG_PROBE_WAVES
-#define MG_PROBE_WAVES 6
+#define MG_PROBE_WAVES 7                        // the scheme-carrying instantiations: 72 registers and 8-12 B of scratch (6 waves: none; 8: round 3 0.99 ms)
+#endif
+#ifndef MG_PROBE_WAVES3
+#define MG_PROBE_WAVES3 MG_PROBE_WAVES
 #endif
 #ifndef MG_PROBE_WAVES0
 #define MG_PROBE_WAVES0 8                       // the scheme-free instantiation (rounds 1 and 4 of the reference cascade) fits 64 registers but for 16 B of scratch
@@ -1805,7 +1808,7 @@ MG_HD uint32_t chunk_meta(uint32_t owner, uint32_t cnt, int ps, int K) {
     return owner | ((cnt - 1) << 8) | ((uint32_t)ps << 14) | ((uint32_t)K << 20) | 0x80000000u;
 }
 template <int RN, int NS>
-__global__ void __launch_bounds__(PB, NS == 0 ? MG_PROBE_WAVES0 : MG_PROBE_WAVES)
+__global__ void __launch_bounds__(PB, NS == 0 ? MG_PROBE_WAVES0 : (NS >= 3 ? MG_PROBE_WAVES3 : MG_PROBE_WAVES))
 k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb,
               LibDev L, RoundDev P, RoundSch RS, unsigned long long* stats,
               ListIn in, ListOut out, uint32_t* fb_list, unsigned long long* fb_n, bool init,
