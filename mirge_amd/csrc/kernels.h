@@ -372,13 +372,17 @@ constexpr int PT_TILE = MG_PT_TILE, PT_BLOCK = 1024;
 constexpr int PT_P2 = MG_PT_P2;                  // fan-out of pass 2 (pass 1: 16 .. 512, by input size)
 constexpr int PT_C2 = MG_PT_C2;                  // records a final partition may hold
 constexpr int pt_log2(int x) { return x <= 1 ? 0 : 1 + pt_log2(x / 2); }
-// hash bits: pass 1 takes the top log2(P1) bits, pass 2 the log2(P2) below them (far above what the LDS tables use)
-inline int pt_shift1(int p1) { return 64 - pt_log2(p1); }
-inline int pt_shift2(int p1) { return 64 - pt_log2(p1) - pt_log2(PT_P2); }
+// Buckets by multiply-shift on the top 32 hash bits x, so that pass 1 can have ANY fan-out P1: x * P1 = bucket * 2^32 +
+// rest; pass 1 takes the bucket, pass 2 the top log2(P2) bits of the rest (uniform inside a bucket, and far above the
+// hash bits the LDS tables use).  sel = 0: pass 1, 1: pass 2.
+MG_HD uint32_t pt_bucket(uint64_t h64, uint32_t p1, int sel) {
+    const uint64_t x = (h64 >> 32) * (uint64_t)p1;
+    return sel ? (uint32_t)x >> (32 - pt_log2(PT_P2)) : (uint32_t)(x >> 32);
+}
 template <int NB>
 __global__ void __launch_bounds__(PT_BLOCK)
 k_part_pass(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ wt_in, const unsigned long long* __restrict__ n_in, uint32_t n_max,
-            uint32_t in_stride, int shift, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ wt_out, unsigned long long* cursor,
+            uint32_t in_stride, uint32_t p1, int sel, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ wt_out, unsigned long long* cursor,
             uint32_t cap_out, unsigned long long* overflow) {
     // blockIdx.y = input partition (its records start in_stride records further on; n_in[p] of them, at most n_max),
     // blockIdx.x = first tile; a block strides over the partition's tiles (the launches give every tile its own block:
@@ -444,7 +448,7 @@ k_part_pass(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
     for (int e = 0; e < PER; ++e) {
         const uint32_t idx = tid + e * PT_BLOCK;
         rank[e] = EMPTY; bk[e] = 0;
-        if (idx < nvalid && trep[e] == idx) { bk[e] = (uint32_t)(h64[e] >> shift) & (NB - 1); rank[e] = atomicAdd(&hist[bk[e]], 1u); }
+        if (idx < nvalid && trep[e] == idx) { bk[e] = pt_bucket(h64[e], p1, sel); rank[e] = atomicAdd(&hist[bk[e]], 1u); }
     }
     __syncthreads();
     if (tid < (uint32_t)NB) {

@@ -498,7 +498,7 @@ inline uint32_t part_grid() {
 // at most ~75 % full when every read is distinct (hashed keys: 2048 is then 13 sigma above the mean).  Fewest, because
 // every partition ends in one atomic on the table's rank counter and those are served one after the other (~12 ns):
 // at 100M reads the fold kernel took 1.68 ms with 131 K partitions -- exactly that chain.
-int part_p1(uint64_t n) { int p1 = 16; while (p1 < 512 && n > (uint64_t)p1 * 400000ull) p1 *= 2; return p1; }
+int part_p1(uint64_t n) { return (int)std::min<uint64_t>(512, std::max<uint64_t>(16, (n + 389999) / 390000)); }
 template <int KW>
 int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64, int sample, const char* tagA, const char* tagB,
                     const uint32_t* d_wt = nullptr, bool allow_part = true) {
@@ -545,13 +545,13 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
         unsigned long long* cur = C.pt_cur.as<unsigned long long>();
         unsigned long long* ovf = cur + ncur - 1;
         kt_begin(c, "collapse_part16", st);
-        auto pass1 = PT_P1 == 16 ? k_part_pass<16> : PT_P1 == 32 ? k_part_pass<32> : PT_P1 == 64 ? k_part_pass<64> : PT_P1 == 128 ? k_part_pass<128> : PT_P1 == 256 ? k_part_pass<256> : k_part_pass<512>;
+        auto pass1 = PT_P1 <= 16 ? k_part_pass<16> : PT_P1 <= 32 ? k_part_pass<32> : PT_P1 <= 64 ? k_part_pass<64> : PT_P1 <= 128 ? k_part_pass<128> : PT_P1 <= 256 ? k_part_pass<256> : k_part_pass<512>;      // (NB = LDS counters: any fan-out up to it)
         const uint32_t g1 = std::min<uint32_t>((n + PT_TILE - 1) / PT_TILE, part_grid());
         const uint32_t g2 = std::min<uint32_t>((C1 + PT_TILE - 1) / PT_TILE, std::max<uint32_t>(1, part_grid() / PT_P1));
         hipLaunchKernelGGL(pass1, dim3(g1, 1), dim3(PT_BLOCK), 0, st, d_keys, d_wt,
-                           (const unsigned long long*)nullptr, n, 0u, pt_shift1(PT_P1), C.pt_k1.as<uint64_t>(), C.pt_w1.as<uint32_t>(), cur, C1, ovf);
+                           (const unsigned long long*)nullptr, n, 0u, (uint32_t)PT_P1, 0, C.pt_k1.as<uint64_t>(), C.pt_w1.as<uint32_t>(), cur, C1, ovf);
         hipLaunchKernelGGL((k_part_pass<PT_P2>), dim3(g2, PT_P1), dim3(PT_BLOCK), 0, st, C.pt_k1.as<uint64_t>(),
-                           C.pt_w1.as<uint32_t>(), (const unsigned long long*)cur, C1, C1, pt_shift2(PT_P1), C.pt_k2.as<uint64_t>(), C.pt_w2.as<uint32_t>(),
+                           C.pt_w1.as<uint32_t>(), (const unsigned long long*)cur, C1, C1, (uint32_t)PT_P1, 1, C.pt_k2.as<uint64_t>(), C.pt_w2.as<uint32_t>(),
                            cur + PT_P1, (uint32_t)PT_C2, ovf);
         kt_end(c, "collapse_part16", (uint64_t)n * 16, st);
         kt_begin(c, "collapse_fold16", st);
