@@ -498,7 +498,8 @@ inline uint32_t part_grid() {
 // at most ~75 % full when every read is distinct (hashed keys: 2048 is then 13 sigma above the mean).  Fewest, because
 // every partition ends in one atomic on the table's rank counter and those are served one after the other (~12 ns):
 // at 100M reads the fold kernel took 1.68 ms with 131 K partitions -- exactly that chain.
-int part_p1(uint64_t n) { return (int)std::min<uint64_t>(512, std::max<uint64_t>(16, (n + 389999) / 390000)); }
+inline uint64_t part_fill() { if (const char* e = getenv("MIRGE_PART_FILL")) { const long v = atol(e); if (v >= 100000 && v <= 500000) return (uint64_t)v; } return 390000; }     // reads per first-pass bucket (tuning aid)
+int part_p1(uint64_t n) { return (int)std::min<uint64_t>(512, std::max<uint64_t>(16, (n + part_fill() - 1) / part_fill())); }
 template <int KW>
 int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64, int sample, const char* tagA, const char* tagB,
                     const uint32_t* d_wt = nullptr, bool allow_part = true) {
