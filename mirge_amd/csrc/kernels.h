@@ -45,6 +45,10 @@ constexpr int CTX_BACK = 16, CTX_NT = 48;
 // so that the FORWARD read is compared against it exactly as against a forward entry -- the matcher never builds a
 // reverse complement, and the strand only shows in the reported position.
 struct __attribute__((aligned(32))) PEnt { uint32_t pos, info, c[6]; };
+// slot of a compact table: a == b: empty bucket; b == CS_SINGLE: the bucket's only entry is a (position | strand);
+// else the bucket's entries are cpos[a, b)
+struct __attribute__((aligned(8))) CSlot { uint32_t a, b; };
+constexpr uint32_t CS_SINGLE = 0xFFFFFFFFu;
 constexpr int PCTX_NT = 96, PCTX_BACK = 40;
 constexpr uint32_t PENT_MAX_REFS = 1u << 20;
 // A table (the contiguous one or one scheme's shape tables) inside the library's slot / occupancy buffers.
@@ -89,6 +93,14 @@ struct LibDev {
     TabDesc   ctab;              // the contiguous table: 4^kb slots
     int32_t   nsch;
     TabDesc   sch[MAX_SCHEMES];  // the block schemes built so far
+    // Compact both-strand tables (cslots == null: none) of a library whose 2-bit text and N bitmap fit the LDS (the
+    // miRNA library: 18 KB + 9 KB).  Same buckets, same TabDesc layout (ctab / sch then describe THESE tables and `slots`
+    // is null), but a slot is 8 bytes and an entry 4: text position | strand.  A candidate is verified against the text
+    // the block staged into LDS, so the whole index of such a library is ~10 MB instead of ~300 MB of 32-byte
+    // self-contained entries, and stays in the L2 / Infinity Cache (k_lds_round).
+    const CSlot*    cslots;
+    const uint32_t* cpos;        // entries of the buckets that hold more than one
+    uint32_t  lds_tw, lds_bw;    // 64-bit words of text / of the N bitmap a block stages (0: not such a library)
 };
 constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu, SLOT_LIST = 0x7FFFFFFFu, POS_REV = 0x80000000u, POS_MASK = 0x7FFFFFFFu;
 
@@ -796,6 +808,26 @@ k_slot_fill(const uint32_t* __restrict__ off, const PEnt* __restrict__ pent, uin
     slot[b] = e;
 }
 
+// the same two steps for a compact table: entries are text position | strand, a slot is the bucket's range or its only entry
+__global__ void __launch_bounds__(256)
+k_both_scatter_pos(const uint64_t* __restrict__ text, uint32_t T, int k, int B, uint32_t mask, uint32_t* cursor, uint32_t* __restrict__ cpos) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < T) {
+        uint32_t bf, br; both_buckets(text, p, k, B, mask, bf, br);
+        cpos[atomicAdd(&cursor[bf], 1u)] = p;
+        cpos[atomicAdd(&cursor[br], 1u)] = p | POS_REV;
+    }
+}
+__global__ void __launch_bounds__(256)
+k_cslot_fill(const uint32_t* __restrict__ off, const uint32_t* __restrict__ cpos, uint64_t nb, CSlot* __restrict__ slot) {
+    uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint32_t lo = off[b], hi = off[b + 1];
+    CSlot e{lo, hi};
+    if (hi == lo + 1) { e.a = cpos[lo]; e.b = CS_SINGLE; }
+    slot[b] = e;
+}
+
 // bucket occupancy bitmap from the histogram: most exact-length lookups of reads that do not belong to
 // a library end in an empty bucket, and this answers them from a structure 32x smaller than koff
 __global__ void __launch_bounds__(256)
@@ -1334,6 +1366,80 @@ __host__ __device__ inline bool probe_one(const uint64_t* key, const LibDev& L, 
     return true;
 }
 
+// ---- the LDS path: libraries with compact tables (LibDev::cslots).  Lookups as on the probe path (same setup, same
+// buckets); a candidate is an entry e = text position of the looked-up window | strand and is verified against the
+// TEXT -- which k_lds_round keeps in LDS -- instead of against a self-contained 32-byte entry.
+MG_HD bool lds_round(const LibDev& L, const RoundDev& P) { return L.cslots != nullptr && round_np(P) <= 3; }
+// reverse complement of a read of l <= 64 nt held in two words
+MG_HD void revcomp2(uint64_t r0, uint64_t r1, int l, uint64_t& c0, uint64_t& c1) {
+    const uint64_t t0 = ~rev2(r1), t1 = ~rev2(r0);               // the reversed complement, left-aligned in 128 bits
+    const int sh = 128 - 2 * l;                                  // >= 0
+    const uint64_t a = sh >= 64 ? t1 : t0, b = sh >= 64 ? 0ull : t1;
+    const int s6 = sh & 63;
+    c0 = s6 ? (a >> s6) | (b << (64 - s6)) : a;
+    c1 = s6 ? b >> s6 : b;
+    c0 &= ones(2 * l); c1 &= ones(2 * l - 64);
+}
+// One entry against a read whose lookup (a window of K nt) started ps nt into it.  q0/q1 = the read (forward entry) or
+// its reverse complement (reverse entry: bit 31 of e); l, s = length and seed length.  true = valid alignment.
+MG_HD bool pos_verify(const RoundDev& P, const uint64_t* text, const uint64_t* bad, uint32_t T, uint64_t q0, uint64_t q1,
+                      int l, int s, int K, int ps, uint32_t e, int& f, int& sm, int& tm, uint32_t& w) {
+    f = (e >> 31) ? 0 : 1;
+    const int64_t ww = (int64_t)(e & POS_MASK) - (f ? ps : l - ps - K);
+    if (ww < 0 || ww + l > (int64_t)T) return false;
+    w = (uint32_t)ww;
+    const uint32_t wi = w >> 5; const int bs = (int)(w & 31) * 2;
+    const uint64_t t0 = text[wi], t1 = text[wi + 1], t2 = text[wi + 2];
+    const uint64_t x0 = bs ? (t0 >> bs) | (t1 << (64 - bs)) : t0, x1 = bs ? (t1 >> bs) | (t2 << (64 - bs)) : t1;
+    uint64_t d0 = x0 ^ q0, d1 = x1 ^ q1;
+    d0 = (d0 | (d0 >> 1)) & M55 & ones(2 * l); d1 = (d1 | (d1 >> 1)) & M55 & ones(2 * l - 64);
+    tm = popc64(d0) + popc64(d1);
+    if (tm > P.maxmm) return false;
+    // the seed = the read's first s nt: the first s of a forward alignment, the last s of the reverse complement
+    const int sa = f ? 0 : l - s, sb = f ? s : l;
+    sm = popc64(d0 & (ones(2 * sb) ^ ones(2 * sa))) + popc64(d1 & (ones(2 * sb - 64) ^ ones(2 * sa - 64)));
+    if (sm > P.seedmm) return false;
+    const uint32_t bi = w >> 6; const int sh = (int)(w & 63);
+    const uint64_t b0 = bad[bi], b1 = bad[bi + 1];
+    const uint64_t rb = sh ? (b0 >> sh) | (b1 << (64 - sh)) : b0;
+    return (rb & ones(l)) == 0;                                  // no reference N, no reference boundary inside the window (l <= 56)
+}
+// the three order keys of the generic matcher (positions, not references): score, max / min position of the best stratum
+struct PosBest { uint64_t score, kmax, kmin; };
+MG_HD void pos_record(PosBest& Bst, int sm, int tm, uint32_t w, int f) {
+    const uint64_t x = hit_score(sm, tm, w, f), y = hit_kmax(sm, w), z = hit_kmin(sm, w);
+    Bst.score = x > Bst.score ? x : Bst.score; Bst.kmax = y > Bst.kmax ? y : Bst.kmax; Bst.kmin = z > Bst.kmin ? z : Bst.kmin;
+}
+constexpr int LDS_MAX_LIST = 4096;
+// Serial form of the LDS path for one read: false = not served (ask the generic matcher).
+__host__ __device__ inline bool lds_one(const uint64_t* key, const LibDev& L, const RoundDev& P, PosBest& Bst) {
+    const RoundSch RS = round_schemes(L, P);
+    ProbeRead R;
+    probe_setup<ROUND_SCHEMES>(key, L, P, RS, R);
+    Bst.score = 0; Bst.kmax = 0; Bst.kmin = 0;
+    if (!R.ok) return true;
+    if (!R.served) return false;
+    uint64_t c0, c1;
+    revcomp2(R.r[0], R.r[1], R.l, c0, c1);
+    const int K = tab_K(R.tab, L);
+    for (int i = 0; i < R.nlook; ++i) {
+        if (!probe_needed(R, P, i, Bst.score)) continue;
+        uint32_t slot, b; int ps;
+        probe_lookup(R, L, i, slot, b, ps);
+        if (tab_bits(R.tab) && !((L.sbits[b >> 5] >> (b & 31)) & 1)) continue;
+        const CSlot sl = L.cslots[slot];
+        if (sl.b != CS_SINGLE && sl.b - sl.a > (uint32_t)LDS_MAX_LIST) return false;
+        const uint32_t n = sl.b == CS_SINGLE ? 1u : sl.b - sl.a;
+        for (uint32_t c = 0; c < n; ++c) {
+            const uint32_t e = sl.b == CS_SINGLE ? sl.a : L.cpos[sl.a + c];
+            int f, sm, tm; uint32_t w;
+            const bool rev = e >> 31;
+            if (pos_verify(P, L.text, L.bad, L.T, rev ? c0 : R.r[0], rev ? c1 : R.r[1], R.l, R.s, K, ps, e, f, sm, tm, w)) pos_record(Bst, sm, tm, w, f);
+        }
+    }
+    return true;
+}
+
 // Serial form of the matcher (one read, all candidates in turn): the definition the kernel below
 // parallelises, and what tests/hostsim runs on the CPU.
 template <int KW>
@@ -1376,6 +1482,15 @@ __host__ __device__ inline void match_generic(const uint64_t* key, const LibDev&
 // the generic matcher.
 template <int KW>
 __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, const RoundDev& P, int32_t& ref, uint32_t& amb) {
+    if (KW == 2 && lds_round(L, P)) {
+        PosBest Bst;
+        if (lds_one(key, L, P, Bst)) {
+            if (!Bst.score) return false;
+            ref = (int32_t)ref_of(L, (uint32_t)(Bst.score >> 1));
+            amb = ref_of(L, (uint32_t)Bst.kmax) != ref_of(L, 0xFFFFFFFFu - (uint32_t)Bst.kmin);
+            return true;
+        }
+    }
     if (KW == 2 && probe_round(L, P)) {
         ProbeBest Bst;
         if (probe_one(key, L, P, Bst)) {
@@ -1756,7 +1871,7 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     // rank counter (new uniques in its high half) the host has not read yet; U is then an upper bound (grid sizing)
     // in: the launch's work (dense, split, or the whole table); list2 (nullable): a second, dense list behind it (what
     // earlier launches of this kernel left of the reads the probe kernel had handed them).  Survivors go to ONE dense list.
-    if (U_dev) U = U0 + (uint32_t)(*U_dev >> 32);
+    if (U_dev) { const uint32_t ud = U0 + (uint32_t)(*U_dev >> 32); U = ud < U ? ud : U; }      // never beyond the bound the launch and its buffers were sized for
     if (in.K > 1) {
         const uint32_t per = in.cap / MB;                  // tiles a sub-list can hold (cap is a multiple of the block size)
         for (uint32_t t = blockIdx.x; t < in.K * per; t += gridDim.x) {
@@ -1818,7 +1933,7 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
               ListIn in, ListOut out, uint32_t* fb_list, unsigned long long* fb_n, bool init,
               const unsigned long long* __restrict__ U_dev, uint32_t U0) {
     constexpr int PQ4 = ProbeQ<NS>::Q4, PQ64 = ProbeQ<NS>::Q64;
-    if (U_dev) U = U0 + (uint32_t)(*U_dev >> 32);               // as in k_match_round
+    if (U_dev) { const uint32_t ud = U0 + (uint32_t)(*U_dev >> 32); U = ud < U ? ud : U; }      // as in k_match_round
     __shared__ unsigned long long s_best[3 * PB];
     __shared__ uint64_t s_r0[PB], s_r1[PB];
     __shared__ uint32_t s_ls[PB];                // l | s << 8
@@ -2021,6 +2136,242 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
 }
 
 // ------------------------------------------------------------------------------------------
+// The LDS path as a kernel (see lds_one for the serial form): a round against a library whose 2-bit text and N bitmap
+// fit the LDS (BASELINE.json's north_star: "library resident in LDS/L2" -- the miRNA library is 18 KB + 9 KB).
+//   * Persistent blocks: each stages text + bitmap into LDS ONCE, then its waves stride over 64-read tiles of the
+//     launch's work.  After the staging there is no block barrier: a wave is a worker of its own, with its own queues
+//     and result words in LDS, so waves never wait for each other's memory round trips.
+//   * Per tile: key -> eligibility -> the read's lookups (probe_setup: pieces, or a block scheme's shapes) -> every
+//     occupancy word, then every 8-byte slot of the read at once (all in flight) -> a bucket's only entry is verified
+//     on the spot; bucket lists are queued: up to LDS_SHORT entries in the short queue (drained 64 / LDS_SHORT lists per
+//     wave step), longer ones in the long queue (64 entries per step, ONE owner, whose read sits in scalar registers).
+//     A list entry is 4 bytes (text position | strand), read coalesced; verification = 5 LDS reads + XOR / popcount.
+//   * Results meet the owner through LDS atomic max on the three order keys of the generic matcher (positions).
+// What the path cannot serve (no fitting scheme, a bucket of more than LDS_MAX_LIST entries) goes on the `fb` list for
+// the generic kernel, as on the probe path.  Lists in / out as k_probe_round (a tile here is 64 reads).
+constexpr int LDS_BLOCK = 512, LDS_WAVES = LDS_BLOCK / 64;
+constexpr int LDS_SHORT = 16;                    // entries of a "short" list
+constexpr int LDS_SQ = 128, LDS_LQ = 64;         // queue capacities per wave (each holds at least one lookup step's lists: 64)
+struct LdsWave {
+    unsigned long long best[3][64];              // score / kmax / kmin of what the drains found, per owner lane
+    uint64_t r0[64], r1[64], c0[64], c1[64];     // the lanes' reads and their reverse complements
+    uint32_t ls[64];                             // l | s << 8
+    uint64_t sq[LDS_SQ], lq[LDS_LQ];             // list descriptors: lo (0-23) | n (24-39) | owner (40-45) | ps (46-51) | K (52-57)
+};
+MG_HD uint64_t lds_desc(uint32_t lo, uint32_t n, uint32_t owner, int ps, int K) {
+    return (uint64_t)lo | ((uint64_t)n << 24) | ((uint64_t)owner << 40) | ((uint64_t)ps << 46) | ((uint64_t)K << 52);
+}
+constexpr uint32_t LDS_MAX_ENTRIES = 1u << 24;   // entries of all compact tables of a library (descriptor: 24 bits)
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in program order; this only keeps the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#ifndef MG_LDS_WAVES
+#define MG_LDS_WAVES 4
+#endif
+template <int RN, int NS>
+__global__ void __launch_bounds__(LDS_BLOCK, MG_LDS_WAVES)
+k_lds_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb,
+            LibDev L, RoundDev P, RoundSch RS, unsigned long long* stats,
+            ListIn in, ListOut out, uint32_t* fb_list, unsigned long long* fb_n, bool init,
+            const unsigned long long* __restrict__ U_dev, uint32_t U0) {
+    constexpr int NL = NS == 0 ? 3 : PROBE_MAX_LOOK;                // lookups a read can have: pieces / a scheme's shapes
+    extern __shared__ uint64_t lds_dyn[];
+    uint64_t* const s_text = lds_dyn;
+    uint64_t* const s_bad = lds_dyn + L.lds_tw;
+    LdsWave* const waves = reinterpret_cast<LdsWave*>(lds_dyn + L.lds_tw + L.lds_bw);
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t j = tid; j < L.lds_tw; j += LDS_BLOCK) s_text[j] = L.text[j];
+    for (uint32_t j = tid; j < L.lds_bw; j += LDS_BLOCK) s_bad[j] = L.bad[j];
+    __syncthreads();
+    if (U_dev) { const uint32_t ud = U0 + (uint32_t)(*U_dev >> 32); U = ud < U ? ud : U; }      // as in k_match_round; never beyond what the launch was sized for
+    LdsWave& W = waves[tid >> 6];
+    const uint32_t gw = blockIdx.x * LDS_WAVES + (tid >> 6), nw = gridDim.x * LDS_WAVES;
+    const uint32_t ndense = (in.p && in.n) ? (uint32_t)*in.n : U;
+    const uint32_t ntiles = in.K > 1 ? in.K * (in.cap / 64) : (ndense + 63) / 64;
+    const unsigned long long below = (1ull << lane) - 1;
+    uint32_t n_act = 0, n_hit = 0;                                  // wave totals, flushed once
+    for (uint32_t t = gw; t < ntiles; t += nw) {
+        const uint32_t* __restrict__ list = in.p;
+        uint32_t n, i0;
+        if (in.K > 1) {
+            const uint32_t sk = t % in.K;
+            n = (uint32_t)in.n[(size_t)sk * LIST_NSTRIDE]; i0 = (t / in.K) * 64; list += (size_t)sk * in.cap;
+        } else { n = ndense; i0 = t * 64; }
+        if (i0 >= n) continue;
+        uint32_t* next_list = out.p;
+        unsigned long long* next_n = out.n;
+        uint32_t next_cap = 0xFFFFFFFFu;
+        if (out.K > 1) {
+            const uint32_t ok = t % out.K;
+            next_list += (size_t)ok * out.cap; next_n += (size_t)ok * LIST_NSTRIDE; next_cap = out.cap;
+        }
+        const uint32_t i = i0 + lane;
+        const uint32_t u = i < n ? (list ? list[i] : i) : EMPTY;
+        uint64_t k[2] = {0, 0};
+        uint8_t done_before = 0;
+        if (u != EMPTY) {
+            if (init) { ann_round[u] = 0; ann_ref[u] = -1; ann_amb[u] = 0; }       // as in k_match_round
+            else if (!list) done_before = ann_round[u];
+            k[0] = ukeys[(uint64_t)u * 2]; k[1] = ukeys[(uint64_t)u * 2 + 1];
+        }
+        const bool listed = u != EMPTY && done_before == 0;
+        bool active = false;
+        if (listed) {
+            const int len = key_len<2>(k);
+            active = !(P.len_lt && !(len < P.len_lt)) && !(P.len_gt && !(len > P.len_gt));
+        }
+        if (!__any(active) && !next_list) continue;
+        if (!active) { k[0] = 0; k[1] = 0; }
+        ProbeRead R;
+        probe_setup<NS>(k, L, P, RS, R);
+        R.ok = R.ok && active;
+        const bool run = R.ok && R.served;
+        bool fb = R.ok && !R.served;
+        uint64_t c0, c1;
+        revcomp2(R.r[0], R.r[1], R.l, c0, c1);
+        W.best[0][lane] = 0; W.best[1][lane] = 0; W.best[2][lane] = 0;
+        W.r0[lane] = R.r[0]; W.r1[lane] = R.r[1]; W.c0[lane] = c0; W.c1[lane] = c1;
+        W.ls[lane] = (uint32_t)(R.l & 255) | ((uint32_t)(R.s & 255) << 8);
+        const int K = tab_K(R.tab, L);
+        const bool ubits = tab_bits(R.tab);
+        // every lookup of the read: occupancy words first, then the slots, all in flight at once
+        uint32_t slot[NL], bb[NL]; int ps[NL]; bool have[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            have[j] = run && j < R.nlook;
+            slot[j] = 0; bb[j] = 0; ps[j] = 0;
+            if (have[j]) probe_lookup(R, L, j, slot[j], bb[j], ps[j]);
+        }
+        uint32_t wd[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) wd[j] = (have[j] && ubits) ? L.sbits[bb[j] >> 5] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) have[j] = have[j] && ((wd[j] >> (bb[j] & 31)) & 1);
+        CSlot sl[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { sl[j] = CSlot{0, 0}; if (have[j]) sl[j] = L.cslots[slot[j]]; }
+        wave_lds_sync();
+
+        PosBest Bst; Bst.score = 0; Bst.kmax = 0; Bst.kmin = 0;     // what this lane finds itself (single-entry buckets)
+        uint32_t sq_n = 0, lq_n = 0;                                // wave-uniform
+        auto judge = [&](uint32_t e, uint32_t owner, int kk, int pss) {
+            const bool rev = e >> 31;
+            const uint64_t q0 = rev ? W.c0[owner] : W.r0[owner], q1 = rev ? W.c1[owner] : W.r1[owner];
+            const uint32_t ls = W.ls[owner];
+            int f, sm, tm; uint32_t w;
+            if (pos_verify(P, s_text, s_bad, L.T, q0, q1, (int)(ls & 255), (int)(ls >> 8), kk, pss, e, f, sm, tm, w)) {
+                atomicMax(&W.best[0][owner], (unsigned long long)hit_score(sm, tm, w, f));
+                atomicMax(&W.best[1][owner], (unsigned long long)hit_kmax(sm, w));
+                atomicMax(&W.best[2][owner], (unsigned long long)hit_kmin(sm, w));
+            }
+        };
+        auto drain_short = [&]() {
+            wave_lds_sync();
+            constexpr int PER = 64 / LDS_SHORT;
+            for (uint32_t base = 0; base < sq_n; base += PER) {
+                const uint32_t q = base + lane / LDS_SHORT, ei = lane % LDS_SHORT;
+                const uint64_t d = q < sq_n ? W.sq[q] : 0ull;
+                if (ei < (uint32_t)((d >> 24) & 0xFFFF)) judge(L.cpos[(uint32_t)(d & 0xFFFFFF) + ei], (uint32_t)(d >> 40) & 63, (int)(d >> 52) & 63, (int)(d >> 46) & 63);
+            }
+            sq_n = 0;
+            wave_lds_sync();
+        };
+        auto drain_long = [&]() {
+            wave_lds_sync();
+            for (uint32_t q = 0; q < lq_n; ++q) {
+                const uint64_t d = W.lq[q];
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(d & 0xFFFFFF));
+                const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((d >> 24) & 0xFFFF));
+                const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(d >> 40));      // owner | ps << 6 | K << 12
+                for (uint32_t c = 0; c < cnt; c += 64)
+                    if (c + lane < cnt) judge(L.cpos[lo + c + lane], meta & 63, (int)(meta >> 12) & 63, (int)(meta >> 6) & 63);
+            }
+            lq_n = 0;
+            wave_lds_sync();
+        };
+        // one lookup per iteration, element 0 of the register arrays (which are shifted down each time: the loop is not
+        // unrolled, so both drains are inlined once); a last iteration without a lookup empties the queues
+#pragma unroll 1
+        for (int j = 0; j <= NL; ++j) {
+            const bool last = j == NL;
+            const bool hv = !last && have[0];
+            const CSlot s0 = sl[0];
+            const int p0 = ps[0];
+#pragma unroll
+            for (int q = 0; q + 1 < NL; ++q) { have[q] = have[q + 1]; sl[q] = sl[q + 1]; ps[q] = ps[q + 1]; }
+            have[NL - 1] = false;
+            if (!last && !__any(hv)) continue;
+            // lookups that what is known by now rules out are dropped (own finds + what the drains so far brought)
+            const uint64_t known = Bst.score > W.best[0][lane] ? Bst.score : W.best[0][lane];
+            const bool need = hv && !fb && probe_needed(R, P, j, known);
+            bool is_s = false, is_l = false;
+            uint32_t cnt = 0;
+            if (need) {
+                if (s0.b == CS_SINGLE) {
+                    const bool rev = s0.a >> 31;
+                    int f, sm, tm; uint32_t w;
+                    if (pos_verify(P, s_text, s_bad, L.T, rev ? c0 : R.r[0], rev ? c1 : R.r[1], R.l, R.s, K, p0, s0.a, f, sm, tm, w)) pos_record(Bst, sm, tm, w, f);
+                } else {
+                    cnt = s0.b - s0.a;
+                    if (cnt > (uint32_t)LDS_MAX_LIST) fb = true;
+                    else if (cnt > (uint32_t)LDS_SHORT) is_l = true;
+                    else if (cnt) is_s = true;
+                }
+            }
+            const unsigned long long ms = __ballot(is_s), ml = __ballot(is_l);
+            if (sq_n && (last || sq_n + (uint32_t)__popcll(ms) > (uint32_t)LDS_SQ)) drain_short();
+            if (is_s) W.sq[sq_n + (uint32_t)__popcll(ms & below)] = lds_desc(s0.a, cnt, lane, p0, K);
+            sq_n += (uint32_t)__popcll(ms);
+            if (lq_n && (last || lq_n + (uint32_t)__popcll(ml) > (uint32_t)LDS_LQ)) drain_long();
+            if (is_l) W.lq[lq_n + (uint32_t)__popcll(ml & below)] = lds_desc(s0.a, cnt, lane, p0, K);
+            lq_n += (uint32_t)__popcll(ml);
+        }
+        wave_lds_sync();
+
+        // ---- results
+        bool hit = false;
+        if (run && !fb) {
+            const unsigned long long a = W.best[0][lane], b2 = W.best[1][lane], c2 = W.best[2][lane];
+            Bst.score = a > Bst.score ? a : Bst.score; Bst.kmax = b2 > Bst.kmax ? b2 : Bst.kmax; Bst.kmin = c2 > Bst.kmin ? c2 : Bst.kmin;
+            if (Bst.score) {
+                hit = true;
+                const uint32_t r = ref_of(L, (uint32_t)(Bst.score >> 1));
+                const uint32_t pmax = (uint32_t)Bst.kmax, pmin = 0xFFFFFFFFu - (uint32_t)Bst.kmin;
+                const uint32_t r0 = L.ref_start[r], r1 = L.ref_start[r + 1];
+                bool amb = false;
+                if (pmin < r0 || pmax >= r1) amb = ref_of(L, pmax) != ref_of(L, pmin);
+                ann_round[u] = (uint8_t)(RN + 1); ann_ref[u] = (int32_t)r; ann_amb[u] = (uint8_t)amb;
+            }
+        }
+        n_act += (uint32_t)__popcll(__ballot(active && !fb)); n_hit += (uint32_t)__popcll(__ballot(hit));
+        const bool surv = next_list != nullptr && listed && !hit && !fb;
+        const unsigned long long sv = __ballot(surv), fv = __ballot(fb);
+        if (sv) {
+            uint32_t base = 0;
+            if (lane == 0) base = (uint32_t)atomicAdd(next_n, (unsigned long long)__popcll(sv));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const uint32_t at = base + (uint32_t)__popcll(sv & below);
+            if (surv && at < next_cap) next_list[at] = u;       // (cannot fail: cap = the tiles that share the sub-list x 64)
+        }
+        if (fv) {
+            uint32_t base = 0;
+            if (lane == 0) base = (uint32_t)atomicAdd(fb_n, (unsigned long long)__popcll(fv));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (fb) fb_list[base + (uint32_t)__popcll(fv & below)] = u;
+        }
+        wave_lds_sync();                                           // the wave's LDS area is rewritten by its next tile
+    }
+    if (lane == 0) {
+        const uint32_t slot_ = gw & (STAT_SLOTS - 1);
+        if (n_act) atomicAdd(&stats[(size_t)slot_ * 8], (unsigned long long)n_act);
+        if (n_hit) atomicAdd(&stats[(size_t)(STAT_SLOTS + slot_) * 8], (unsigned long long)n_hit);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // count vectors (miRge.pl:465-493) over one sample's (unique id, count) entries.
 // Per-block partial sums live in LDS (category totals, length histogram, and -- when the
 // miRNA library is small enough -- the whole quant/iscan column), then one flush of atomics.
@@ -2035,7 +2386,7 @@ k_counts(const uint32_t* __restrict__ coo_g, const uint32_t* __restrict__ coo_c,
          unsigned long long* cat, unsigned long long* lenhist, unsigned long long* tuniq,
          const unsigned long long* __restrict__ n_dev) {
     extern __shared__ unsigned long long s_dyn[];
-    if (n_dev) n = (uint32_t)(*n_dev & 0xFFFFFFFFull);          // the entry count is still on the device (low half of the collapse's rank counter); n was an upper bound
+    if (n_dev) { const uint32_t nd = (uint32_t)(*n_dev & 0xFFFFFFFFull); n = nd < n ? nd : n; }      // the entry count is still on the device (low half of the collapse's rank counter); n was an upper bound
     __shared__ unsigned long long s_cat[5];
     __shared__ unsigned long long s_len[128];
     __shared__ unsigned long long s_tu;

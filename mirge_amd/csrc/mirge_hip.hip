@@ -98,6 +98,9 @@ struct Lib {
     // both-strand slot tables (LibDev::slots ...): the contiguous one is built with the library, the block-scheme ones
     // the first time a cascade holds a round that can use them (ensure_schemes); all in two buffers
     DevBuf slots, sbits, pent, ppre; uint64_t n_slots = 0, n_bitw = 0, n_pent = 0; bool has_both = false;
+    // compact form of the same tables (kernels.h: LibDev::cslots) for a library whose text fits the LDS: 8-byte slots,
+    // 4-byte entries; n_slots / n_bitw / n_pent, ctab and sch then count and describe these
+    DevBuf cslots, cpos; bool has_compact = false; uint32_t lds_tw = 0, lds_bw = 0;
     TabDesc ctab{0, 0, 0}; std::vector<TabDesc> sch;
     LibDev dev() const {
         LibDev L;
@@ -108,9 +111,11 @@ struct Lib {
         L.slots = has_both ? slots.as<PEnt>() : nullptr; L.sbits = sbits.as<uint32_t>(); L.pent = pent.as<PEnt>(); L.ppre = ppre.as<uint64_t>(); L.ctab = ctab;
         L.nsch = (int)sch.size();
         for (int j = 0; j < MAX_SCHEMES; ++j) L.sch[j] = j < L.nsch ? sch[j] : TabDesc{0, 0, 0};
+        L.cslots = has_compact ? cslots.as<CSlot>() : nullptr; L.cpos = cpos.as<uint32_t>();
+        L.lds_tw = has_compact ? lds_tw : 0; L.lds_bw = has_compact ? lds_bw : 0;
         return L;
     }
-    void release() { text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); slots.release(); sbits.release(); pent.release(); ppre.release(); sch.clear(); n_slots = n_bitw = n_pent = 0; has_both = false; loaded = false; }
+    void release() { cslots.release(); cpos.release(); has_compact = false; text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); slots.release(); sbits.release(); pent.release(); ppre.release(); sch.clear(); n_slots = n_bitw = n_pent = 0; has_both = false; loaded = false; }
 };
 
 constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
@@ -294,13 +299,18 @@ bool bits_wanted(uint64_t nbk) {                 // an occupancy bitmap in front
 // One table: 2T entries (every position under its own key and under the reverse strand's) appended to `pent`, nbk = 4^k
 // slots and nbk / 32 occupancy words appended to the library's slot / occupancy buffers (all grown here).
 // B = 0: the contiguous k-mer table; else the table of one shape (block mask) of a block scheme.
-int build_both(mirge_ctx* c, Lib& L, int k, int B, uint32_t mask) {
+int build_both(mirge_ctx* c, Lib& L, int k, int B, uint32_t mask, bool compact = false) {
     const uint64_t nbk = 1ull << (2 * k), T = L.T, base = L.n_pent;
     if (base + 2 * T >= 0xFFFFFFF0ull || L.n_slots + nbk >= 0xFFFFFFF0ull || L.n_bitw + nbk / 32 >= (1ull << 27))
         return fail(c, MIRGE_E_LIMIT, "seed tables of a library exceed 2^32 entries");
+    if (compact) {
+        HIPCHK(c, L.cpos.ensure((base + 2 * T) * 4, true, base * 4, c->st));
+        HIPCHK(c, L.cslots.ensure((L.n_slots + nbk) * sizeof(CSlot), true, L.n_slots * sizeof(CSlot), c->st));
+    } else {
     HIPCHK(c, L.pent.ensure((base + 2 * T) * sizeof(PEnt), true, base * sizeof(PEnt), c->st));
     HIPCHK(c, L.ppre.ensure((base + 2 * T) * 8, true, base * 8, c->st));
     HIPCHK(c, L.slots.ensure((L.n_slots + nbk) * sizeof(PEnt), true, L.n_slots * sizeof(PEnt), c->st));
+    }
     HIPCHK(c, L.sbits.ensure((L.n_bitw + nbk / 32 + 1) * 4, true, L.n_bitw * 4, c->st));
     HIPCHK(c, c->hist.ensure((nbk + 1) * 4, false, 0, c->st));
     HIPCHK(c, c->off_tmp.ensure((nbk + 1) * 4, false, 0, c->st));
@@ -312,9 +322,14 @@ int build_both(mirge_ctx* c, Lib& L, int k, int B, uint32_t mask) {
     if (rc) return rc;
     hipLaunchKernelGGL(k_add_u32, dim3((uint32_t)((nbk + 1 + 255) / 256)), dim3(256), 0, c->st, c->off_tmp.as<uint32_t>(), nbk + 1, (uint32_t)base);
     HIPCHK(c, hipMemcpyAsync(c->hist.p, c->off_tmp.p, nbk * 4, hipMemcpyDeviceToDevice, c->st));
+    if (compact) {
+        hipLaunchKernelGGL(k_both_scatter_pos, dim3(grid), dim3(256), 0, c->st, L.text.as<uint64_t>(), (uint32_t)T, k, B, mask, c->hist.as<uint32_t>(), L.cpos.as<uint32_t>());
+        hipLaunchKernelGGL(k_cslot_fill, dim3((uint32_t)((nbk + 255) / 256)), dim3(256), 0, c->st, c->off_tmp.as<uint32_t>(), L.cpos.as<uint32_t>(), nbk, L.cslots.as<CSlot>() + L.n_slots);
+    } else {
     hipLaunchKernelGGL(k_both_scatter, dim3(grid), dim3(256), 0, c->st, L.dev(), k, B, mask, c->hist.as<uint32_t>(), L.pent.as<PEnt>());
     hipLaunchKernelGGL(k_slot_fill, dim3((uint32_t)((nbk + 255) / 256)), dim3(256), 0, c->st, c->off_tmp.as<uint32_t>(), L.pent.as<PEnt>(), nbk, L.slots.as<PEnt>() + L.n_slots);
     hipLaunchKernelGGL(k_pent_pre, dim3((uint32_t)((2 * T + 255) / 256)), dim3(256), 0, c->st, L.pent.as<PEnt>() + base, 2 * T, L.ppre.as<uint64_t>() + base);
+    }
     HIPCHK(c, hipGetLastError());
     L.n_pent = base + 2 * T; L.n_slots += nbk; L.n_bitw += nbk / 32;
     return MIRGE_OK;
@@ -329,16 +344,36 @@ int build_contig_both(mirge_ctx* c, Lib& L) {
     L.has_both = true;
     return MIRGE_OK;
 }
+// A library whose text + N bitmap a block can stage into LDS next to its waves' queues takes the compact tables and
+// k_lds_round.  MIRGE_LDS = 0: never (A/B aid); MIRGE_LDS_MAX = bytes of text + bitmap (default 40 KB: two blocks per CU).
+uint64_t lds_lib_max() { if (const char* e = getenv("MIRGE_LDS_MAX")) return strtoull(e, nullptr, 10); return 40u << 10; }
+bool lds_wanted(const Lib& L) {
+    if (const char* e = getenv("MIRGE_LDS")) { if (atoi(e) == 0) return false; }
+    if (L.T == 0) return false;
+    const uint64_t tw = L.T / 32 + 3, bw = L.T / 64 + 2;
+    // entries of every table the library can get: the contiguous one + schemes (4,1), (5,2), (4,2), (3,2) = 1 + 4 + 18
+    return (tw + bw) * 8 <= lds_lib_max() && 2 * L.T * 23 < LDS_MAX_ENTRIES;
+}
+int build_contig_compact(mirge_ctx* c, Lib& L) {
+    const uint64_t nbk = 1ull << (2 * L.kb);
+    // an occupancy bitmap in front of the slots pays where most buckets are empty (it is 1/64 of the slots' bytes)
+    L.ctab = TabDesc{(uint32_t)L.n_slots, (uint32_t)L.n_bitw, tab_info(L.kb, 0, 0, nbk >= 8 * L.T)};
+    int rc = build_both(c, L, L.kb, 0, 0u, true);
+    if (rc) return rc;
+    L.has_compact = true; L.lds_tw = (uint32_t)(L.T / 32 + 3); L.lds_bw = (uint32_t)(L.T / 64 + 2);
+    return MIRGE_OK;
+}
 // Block scheme (B, m) of a library (kernels.h: block schemes), built the first time a cascade holds a round that can use it.
 int ensure_scheme(mirge_ctx* c, Lib& L, int B, int m) {
-    if (!L.loaded || !L.has_both || L.T == 0) return MIRGE_OK;
+    if (!L.loaded || !(L.has_both || L.has_compact) || L.T == 0) return MIRGE_OK;
     for (auto& x : L.sch) if (tab_B(x) == B && tab_m(x) == m) return MIRGE_OK;
     if ((int)L.sch.size() >= MAX_SCHEMES) return MIRGE_OK;
     const int ns = scheme_nshapes(m), kbs = std::min((4 - m) * B, L.kb);
     const uint64_t nbk = 1ull << (2 * kbs);
     if (L.n_pent + (uint64_t)ns * 2 * L.T >= 0xFFFFFFF0ull || L.n_slots + ns * nbk >= 0xFFFFFFF0ull) return MIRGE_OK;    // too large a library: its short reads stay with the generic kernel
-    const TabDesc t{(uint32_t)L.n_slots, (uint32_t)L.n_bitw, tab_info(kbs, B, m, bits_wanted(nbk))};
-    for (int i = 0; i < ns; ++i) { int rc = build_both(c, L, kbs, B, scheme_shape(m, i)); if (rc) return rc; }
+    if (L.has_compact && L.n_pent + (uint64_t)ns * 2 * L.T >= LDS_MAX_ENTRIES) return MIRGE_OK;
+    const TabDesc t{(uint32_t)L.n_slots, (uint32_t)L.n_bitw, tab_info(kbs, B, m, L.has_compact ? nbk >= 8 * L.T : bits_wanted(nbk))};
+    for (int i = 0; i < ns; ++i) { int rc = build_both(c, L, kbs, B, scheme_shape(m, i), L.has_compact); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->st));
     L.sch.push_back(t);
     return MIRGE_OK;
@@ -388,7 +423,7 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     for (auto& nm : L.names) { size_t e = nm.find_first_of(" \t"); L.short_names.push_back(e == std::string::npos ? nm : nm.substr(0, e)); }
     int kb = (int)std::lround(std::log2((double)std::max<uint64_t>(T, 16)) / 2.0) + 1;   // ~0.25 random entries per bucket
     L.kb = std::min(14, std::max(4, kb));
-    L.use_bits = true; L.has_both = false; L.sch.clear(); L.n_slots = L.n_bitw = L.n_pent = 0;
+    L.use_bits = true; L.has_both = false; L.has_compact = false; L.sch.clear(); L.n_slots = L.n_bitw = L.n_pent = 0;
     int kb_max = 14;
     if (const char* env = getenv("MIRGE_KB_MAX")) kb_max = std::min(15, std::max(4, atoi(env)));         // tuning aid
     L.kb = std::min(kb_max, std::max(4, kb));
@@ -429,7 +464,8 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
         HIPCHK(c, hipGetLastError());
         int min_kb = 9;
         if (const char* env = getenv("MIRGE_SLOTS_MIN_KB")) min_kb = atoi(env);
-        if (L.kb >= min_kb && want_slots()) { rc = build_contig_both(c, L); if (rc) return rc; }
+        if (want_slots() && lds_wanted(L)) { rc = build_contig_compact(c, L); if (rc) return rc; }
+        else if (L.kb >= min_kb && want_slots()) { rc = build_contig_both(c, L); if (rc) return rc; }
     } else {
         HIPCHK(c, hipMemsetAsync(L.koff.p, 0, (nb + 1) * 4, c->st));
     }
@@ -1191,6 +1227,31 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
     // the lists of the generic kernel's own leftovers (16-byte class, probe rounds): read whenever an earlier round wrote any
     const bool had_list = ll ? r >= 3 : r >= 2;
     const uint32_t* fbs_in = (KW == 2 && had_list) ? C.fbs[(r + 1) & 1].as<uint32_t>() : (const uint32_t*)nullptr;
+    if (KW == 2 && lds_round(L, P)) {
+        // the LDS path (kernels.h: k_lds_round): persistent blocks with the library's text in LDS, then the generic
+        // kernel over the reads it handed on
+        const RoundSch RS = round_schemes(L, P);
+        auto kern = RS.n == 0 ? k_lds_round<RN, 0> : (RS.n == 1 ? k_lds_round<RN, 1> : k_lds_round<RN, ROUND_SCHEMES>);
+        const size_t lds = ((size_t)L.lds_tw + L.lds_bw) * 8 + (size_t)LDS_WAVES * sizeof(LdsWave);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const uint64_t tiles = in.K > 1 ? (uint64_t)in.K * (in.cap / 64) : (UB + 63) / 64;
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160u << 10) / (lds + 512)));
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->n_cu * per_cu, (tiles + LDS_WAVES - 1) / LDS_WAVES));
+        const uint32_t cap_out = (uint32_t)(((tiles + LIST_K - 1) / LIST_K * 64 + PB - 1) / PB * PB);      // tiles that share a sub-list x 64, in whole blocks of the reader
+        ListOut out{nullptr, nullptr, 0, 0};
+        if (writes) { out = ListOut{C.act[r & 1].as<uint32_t>(), cnt_out, (uint32_t)LIST_K, cap_out}; C.lf[r + 1].K = LIST_K; C.lf[r + 1].cap = cap_out; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(LDS_BLOCK), lds, C.st,
+                           C.ukeys.as<uint64_t>(), (uint32_t)UB, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), C.ann_amb.as<uint8_t>(),
+                           L, P, RS, c->d_stats + (size_t)r * STAT_WORDS, in, out,
+                           C.fb.as<uint32_t>(), C.fb_n + r, init, U_dev, (uint32_t)C.U);
+        hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)std::min<uint64_t>((UB + MB - 1) / MB, 512)), dim3(MB), 0, C.st,
+                           C.ukeys.as<uint64_t>(), (uint32_t)UB, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
+                           C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
+                           ListIn{C.fb.as<uint32_t>(), C.fb_n + r, 1, 0}, fbs_in, (const unsigned long long*)(C.fbs_n + r),
+                           writes ? C.fbs[r & 1].as<uint32_t>() : (uint32_t*)nullptr, C.fbs_n + r + 1, false,
+                           U_dev, (uint32_t)C.U);
+        return;
+    }
     if (KW == 2 && probe_round(L, P)) {
         // the probe path (kernels.h: k_probe_round) for what the slot tables can serve, then the generic kernel over the
         // reads it handed on
@@ -1342,8 +1403,8 @@ int annotate(mirge_ctx* c) {
         HIPCHK(c, C.ann_round.ensure(U, false, 0, c->st));
         HIPCHK(c, C.ann_ref.ensure(U * 4, false, 0, c->st));
         HIPCHK(c, C.ann_amb.ensure(U, false, 0, c->st));
-        HIPCHK(c, C.act[0].ensure((U + (size_t)LIST_K * PB) * 4, false, 0, c->st));      // (a split list: LIST_K sub-lists, each rounded up to whole blocks)
-        HIPCHK(c, C.act[1].ensure((U + (size_t)LIST_K * PB) * 4, false, 0, c->st));
+        HIPCHK(c, C.act[0].ensure((U + (size_t)LIST_K * 2 * PB) * 4, false, 0, c->st));      // (a split list: LIST_K sub-lists, each rounded up to whole tiles, then to whole blocks)
+        HIPCHK(c, C.act[1].ensure((U + (size_t)LIST_K * 2 * PB) * 4, false, 0, c->st));
         if (k == 0) {
             HIPCHK(c, C.fb.ensure(U * 4, false, 0, c->st));
             HIPCHK(c, C.fbs[0].ensure(U * 4, false, 0, c->st));

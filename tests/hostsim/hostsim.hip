@@ -16,18 +16,21 @@ struct SimLib {
     std::vector<uint32_t> koff, ref_start, kbits, lut; int lut_shift = 5; std::vector<KEnt> kent; std::vector<uint64_t> kpre;
     uint32_t T; int kb;
     std::vector<PEnt> slots, pent; std::vector<uint32_t> sbits; TabDesc ctab{0, 0, 0}; std::vector<TabDesc> sch;
+    std::vector<CSlot> cslots; std::vector<uint32_t> cpos;
     LibDev dev() const { LibDev L; L.text = text.data(); L.bad = bad.data(); L.koff = koff.data(); L.kent = kent.data(); L.kpre = kpre.data(); L.kbits = kbits.data();
                          L.ref_start = ref_start.data(); L.ref_lut = lut.data(); L.lut_shift = lut_shift; L.n_refs = (uint32_t)ref_start.size() - 1; L.T = T; L.kb = kb;
                          L.slots = slots.empty() ? nullptr : slots.data(); L.sbits = sbits.data(); L.pent = pent.data(); L.ppre = nullptr; L.ctab = ctab;
                          L.nsch = (int)sch.size();
                          for (int j = 0; j < MAX_SCHEMES; ++j) L.sch[j] = j < L.nsch ? sch[j] : TabDesc{0, 0, 0};
+                         L.cslots = cslots.empty() ? nullptr : cslots.data(); L.cpos = cpos.data(); L.lds_tw = T / 32 + 3; L.lds_bw = T / 64 + 2;
                          return L; }
 };
 
 extern "C" {
 
 // same layout rules as load_library() in mirge_hip.hip; index built with text_kmer()
-// flags bit 0: the both-strand slot tables as well (LibDev::kslot, and the block schemes (4,1), (5,2), (4,2), (3,2)), bit 1: no occupancy bits in front of them
+// flags bit 0: the both-strand slot tables as well (LibDev::kslot, and the block schemes (4,1), (5,2), (4,2), (3,2)), bit 1: no occupancy bits in front of them,
+// bit 2: the tables in their compact form (LibDev::cslots: the LDS path, lds_one)
 void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb, int32_t flags) {
     SimLib* S = new SimLib();
     uint64_t T = 0;
@@ -57,9 +60,27 @@ void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb,
     for (uint32_t q = 0; q < T; ++q) S->kent[cur[text_kmer(S->text.data(), q, kb)]++] = make_kent(S->text.data(), q);
     // both-strand slot tables, laid out as build_contig_both() / ensure_scheme() in mirge_hip.hip do
     if ((flags & 1) && T > 0) {
-        const bool ubits = !(flags & 2);
+        const bool ubits = !(flags & 2), compact = flags & 4;
         const LibDev LD = S->dev();                                      // text, N bitmap and reference offsets are in place
-        auto build = [&](int k, int B, uint32_t mask) {
+        auto build_c = [&](int k, int B, uint32_t mask) {                // as build_both(..., compact) in mirge_hip.hip
+            const uint64_t nbk = 1ull << (2 * k), base = S->cpos.size(), s0 = S->cslots.size(), w0 = S->sbits.size();
+            S->cpos.resize(base + 2 * (size_t)T); S->cslots.resize(s0 + nbk); S->sbits.resize(w0 + nbk / 32, 0);
+            std::vector<uint32_t> off(nbk + 1, 0);
+            for (uint32_t q = 0; q < T; ++q) { uint32_t bf, br; both_buckets(S->text.data(), q, k, B, mask, bf, br); off[bf + 1]++; off[br + 1]++; }
+            for (uint64_t b = 0; b < nbk; ++b) { if (off[b + 1]) S->sbits[w0 + (b >> 5)] |= 1u << (b & 31); off[b + 1] += off[b]; }
+            for (auto& o : off) o += (uint32_t)base;
+            std::vector<uint32_t> cur2(off.begin(), off.end() - 1);
+            for (uint32_t q = 0; q < T; ++q) {
+                uint32_t bf, br; both_buckets(S->text.data(), q, k, B, mask, bf, br);
+                S->cpos[cur2[bf]++] = q; S->cpos[cur2[br]++] = q | POS_REV;
+            }
+            for (uint64_t b = 0; b < nbk; ++b) {                        // as k_cslot_fill
+                CSlot e{off[b], off[b + 1]};
+                if (e.b == e.a + 1) { e.a = S->cpos[off[b]]; e.b = CS_SINGLE; }
+                S->cslots[s0 + b] = e;
+            }
+        };
+        auto build_p = [&](int k, int B, uint32_t mask) {
             const uint64_t nbk = 1ull << (2 * k), base = S->pent.size(), s0 = S->slots.size(), w0 = S->sbits.size();
             const int K = B ? 4 * B : k;
             S->pent.resize(base + 2 * (size_t)T);
@@ -82,12 +103,13 @@ void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb,
                 S->slots[s0 + b] = e;
             }
         };
+        auto build = [&](int k, int B, uint32_t mask) { if (compact) build_c(k, B, mask); else build_p(k, B, mask); };
         S->ctab = TabDesc{0, 0, tab_info(kb, 0, 0, ubits)};
         build(kb, 0, 0u);
         const int BM[4][2] = {{4, 1}, {5, 2}, {4, 2}, {3, 2}};
         for (int j = 0; j < 4; ++j) {
             const int B = BM[j][0], m = BM[j][1], kbs = std::min((4 - m) * B, kb);
-            S->sch.push_back(TabDesc{(uint32_t)S->slots.size(), (uint32_t)S->sbits.size(), tab_info(kbs, B, m, ubits)});
+            S->sch.push_back(TabDesc{(uint32_t)(compact ? S->cslots.size() : S->slots.size()), (uint32_t)S->sbits.size(), tab_info(kbs, B, m, ubits)});
             for (int i = 0; i < scheme_nshapes(m); ++i) build(kbs, B, scheme_shape(m, i));
         }
         S->sbits.push_back(0);

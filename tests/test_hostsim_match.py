@@ -78,7 +78,8 @@ def _reads_from(rng, seqs, n, lo, hi, with_n=False):
 
 # flags: 0 = the one-strand CSR index only (small libraries), 1 = both-strand slot tables (+ gapped seed tables at
 # kb >= 9: reads with 16..2*kb-1 seed nt), 3 = the same without occupancy bits in front of the slots
-@pytest.mark.parametrize("flags", [0, 1, 3])
+# 5 / 7 = the same tables in their compact form (4-byte entries, candidates verified on the text: the LDS path)
+@pytest.mark.parametrize("flags", [0, 1, 3, 5, 7])
 @pytest.mark.parametrize("seed,kb,with_n,lo,hi", [
     (1, 4, False, 16, 47), (2, 6, False, 16, 47), (3, 8, False, 16, 56), (4, 5, True, 16, 60),
     (5, 7, True, 50, 124), (6, 4, False, 1, 20), (7, 10, False, 16, 47), (8, 3, True, 3, 30),
