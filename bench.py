@@ -214,7 +214,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_plain(n_steps, **kw):
+        """The timed region of `value`: K steps between two fences, per-kernel event records switched off (each named
+        kernel time is two markers on the stream; ~40 of them per step sit between the kernels)."""
+        ctx.set_kernel_timing(False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step(**kw)
+        fence()
+        el = time.perf_counter() - t0
+        ctx.set_kernel_timing(True)
+        return el
+
     def timed(n_steps, **kw):
+        """The same steps once more WITH the per-kernel HIP events (on the library's own streams): the kernel breakdown
+        and the roofline figures come from here, never `value`."""
         fence()
         t0 = time.perf_counter()
         dev_ms, kts = [], []
@@ -235,7 +250,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    elapsed, dev_ms, ktimes = timed(args.steps)
+    elapsed = timed_plain(args.steps)
+    elapsed_events, dev_ms, ktimes = timed(args.steps)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if not rehearsal else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -263,15 +279,26 @@ def main():
     dom = max(kavg, key=lambda k: kavg[k][0])
     dom_ms, dom_bytes, _ = kavg[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    traffic = None
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is the
+    # builder's rocprofv3 pass over this same command (committed file), and it is reported only when that file says it was
+    # taken from the same workload AND the same build of the library (sha256 of the .so); else null
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
+            import hashlib
             tj = json.load(open(tpath))
-            if tj.get("reads") == N and tj.get("profile") == args.profile:
+            so = os.environ.get("MIRGE_HIP_LIB") or os.path.join(ROOT, "mirge_amd", "libmirge_hip.so")
+            sha = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]
+            if tj.get("reads") == N and tj.get("profile") == args.profile and tj.get("lib_sha16") == sha:
                 traffic = tj.get("kernels", {}).get(dom)
+                traffic_source = ("profiles/pmc_traffic.json: the builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command with "
+                                  "this build of the library (lib_sha16 %s), not counters of this run; 2*FETCH + WRITE KiB, i.e. bytes past "
+                                  "the L2 -- Infinity Cache hits included" % sha)
+            else:
+                traffic_source = "profiles/pmc_traffic.json is of another build or workload: not reported"
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
     dev_ms_avg, dev_ms_med = float(np.mean(dev_ms)), float(np.median(dev_ms))
 
     if world == 1:
@@ -296,7 +323,7 @@ def main():
                    "round_uniques": [int(s[0]) for s in stats], "round_aligned": [int(s[1]) for s in stats],
                    "parallelism": "shard%d%s%s" % (world, "+merge_uniques" if merge else "", "+gloo_one_device_rehearsal" if rehearsal and world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "copy_measured": copy_gbs, "frac_of_copy": achieved / copy_gbs,
                      "kernel_ms": dom_ms, "kernel_bytes_alg": dom_bytes,
                      "note": "achieved = SURVEY.md 8d's algorithmic bytes of the kernel / its HIP-event time: an index-based matcher cannot "
@@ -305,6 +332,7 @@ def main():
         "roofline_path": {"bytes_alg_per_read": b_alg / n_job, "device_ms": dev_ms_avg, "device_ms_median": dev_ms_med,
                           "achieved": b_alg / world / (dev_ms_avg * 1e-3) / 1e9 if dev_ms_avg > 0 else 0.0,
                           "frac": (b_alg / world / (dev_ms_avg * 1e-3) / 1e9) / HBM_PEAK_GBS if dev_ms_avg > 0 else 0.0},
+        "ms_per_step_with_kernel_events": 1e3 * elapsed_events / args.steps,
         "kernels_ms": {k: round(v[0], 4) for k, v in kavg.items()},
         "kernels_ms_median": {k: round(v[2], 4) for k, v in kavg.items()},
         "setup": {"index_build_s": round(t_index, 3), "h2d_bytes": int(h2d_bytes)},
@@ -324,7 +352,7 @@ def main():
     # ---- CPU baseline on a bounded sample: the reference's own tools when the box has them, else the oracle (a port)
     if solo and args.cpu_sample > 0 and first is not None:
         from oracle import oracle as orc
-        cores = min(16, os.cpu_count() or 1)
+        cores = min(16, os.cpu_count() or 1)                    # threads used; the box's count goes beside it (cores_on_box)
         sample_seqs, sample_lens = first
         ref = reference_cpu_leg(synth, libs, sample_seqs[:1_000_000], sample_lens[:1_000_000], cores)
         olibs = [orc.OracleLib((libs[nm].text, libs[nm].offs)) for nm in synth.LIB_NAMES]   # index build: not timed
@@ -337,6 +365,7 @@ def main():
         out["cpu_baseline"] = ref or port
         out["cpu_baseline"]["reference_published"] = {"value": REF_PUBLISHED_READS_PER_S, "unit": "reads/s",
                                                       "note": "miRge's own example run (cascade only, hardware and threads not stated): report.html:170-175"}
+        out["cpu_baseline"]["cores_on_box"] = os.cpu_count()
         out["cpu_baseline"]["tools_found"] = {t: tool_version(t) for t in ("bowtie", "bowtie-build", "cutadapt")}
         if ref:
             out["cpu_baseline_port"] = port
@@ -355,8 +384,9 @@ def main():
                                                    synth.Mixture.realistic(), W, rank, label="reads (realistic mixture)")
         kw = dict(a=rk16, na=rn16, b=rk48, nb=rn48)
         step(**kw); step(**kw)
-        el, dms, kts = timed(max(3, args.steps // 2), **kw)
         nst = max(3, args.steps // 2)
+        el = timed_plain(nst, **kw)
+        _, dms, kts = timed(nst, **kw)
         rs = [ctx.round_stats(r + 1) for r in range(5)]
         out["realistic"] = {"reads": int(args.realistic_reads), "uniques": int(ctx.n_unique()), "unique_fraction": ctx.n_unique() / args.realistic_reads,
                             "reads_per_s": args.realistic_reads * nst / el, "ms_per_step": 1e3 * el / nst,

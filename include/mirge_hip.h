@@ -251,6 +251,11 @@ int32_t     mirge_last_timing(const mirge_ctx*, double* collapse_ms, double* ann
 /* Named per-kernel device times of the last calls: fills up to cap entries,
  * returns how many exist.  names[i] points at a static string. */
 int32_t     mirge_kernel_times(const mirge_ctx*, const char** names, double* ms, uint64_t* bytes_alg, int32_t cap);
+/* Per-kernel timing on (default) / off.  Each named time costs two event records on the stream -- markers between the
+ * kernels of a step, ~40 of them per collapse + cascade; a caller that only wants results switches them off
+ * (mirge_kernel_times then reports nothing, mirge_last_timing and the per-round seconds of mirge_round_stats -- the
+ * cpuTime column of miRge.pl:352-354 -- report 0).  No counterpart in the reference. */
+int32_t     mirge_set_kernel_timing(mirge_ctx*, int32_t on);
 
 #ifdef __cplusplus
 }

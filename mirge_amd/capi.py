@@ -28,7 +28,7 @@ EXPORTS = [
     "mirge_collapse_packed_dev", "mirge_annotate", "mirge_round_stats", "mirge_counts", "mirge_counts_flat_len",
     "mirge_counts_flat_get", "mirge_counts_flat_set", "mirge_counts_flat_get_dev", "mirge_counts_flat_set_dev", "mirge_validate_keys_dev", "mirge_collapse_annotate_packed_dev", "mirge_n_unique", "mirge_max_unique_len", "mirge_unique", "mirge_export_uniques",
     "mirge_verb_export_size", "mirge_verb_export", "mirge_verb_clear", "mirge_verb_import",
-    "mirge_n_counts", "mirge_export_counts", "mirge_last_timing", "mirge_kernel_times", "mirge_write_tables",
+    "mirge_n_counts", "mirge_export_counts", "mirge_last_timing", "mirge_kernel_times", "mirge_set_kernel_timing", "mirge_write_tables",
     "mirge_collapse_keys16_noalloc",
 ]
 
@@ -112,6 +112,7 @@ def load():
     L.mirge_export_counts.argtypes = [vp, vp, vp, vp]
     L.mirge_last_timing.argtypes = [vp] + [C.POINTER(C.c_double)] * 3
     L.mirge_kernel_times.argtypes = [vp, vp, vp, vp, i32]
+    L.mirge_set_kernel_timing.argtypes = [vp, i32]
     _lib = L
     return L
 
@@ -353,6 +354,9 @@ class Context:
         return seq.value.decode(), list(refs), amb.value, [cnt[s] for s in range(self.S)]
 
     # ---- timing
+    def set_kernel_timing(self, on):
+        self._chk(self.L.mirge_set_kernel_timing(self.h, 1 if on else 0))
+
     def last_timing(self):
         a = C.c_double(); b = C.c_double(); c = C.c_double()
         self._chk(self.L.mirge_last_timing(self.h, C.byref(a), C.byref(b), C.byref(c)))

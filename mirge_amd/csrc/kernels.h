@@ -55,15 +55,23 @@ constexpr uint32_t PENT_MAX_REFS = 1u << 20;
 struct TabDesc {
     uint32_t slot_off;           // first slot (LibDev::slots); a scheme's shape i starts nbk * i further on
     uint32_t bits_off;           // first occupancy word (LibDev::sbits); shape i starts nbk / 32 * i further on
-    uint32_t info;               // kbs (0-7) | B (8-15; 0 = contiguous) | m (16-23) | occupancy bits in use (24)
+    uint32_t info;               // kbs (0-7) | m (8-11) | occupancy bits in use (12) | blocks (16-31; 0 = contiguous)
 };
+// A scheme's four blocks, 4 bits each, block 0 (the read's first nt) in the low bits.  Equal blocks (B, B, B, B) are the
+// original schemes; unequal ones let a scheme's window be EXACTLY a short read's length: a 13-nt read under (4,3,3,3)
+// makes six lookups keyed by 6-7 nt (~9-36 entries per bucket of the miRNA library) where (3,3,3,3) over its first 12 nt
+// made six keyed by 6 nt (~36 each); a 15-nt read under (4,4,4,3) six keyed by 7-8 nt (~2-9 each).
+MG_HD uint32_t blocks_eq(int B) { return (uint32_t)B * 0x1111u; }
+MG_HD int blk(uint32_t bl, int j) { return (int)((bl >> (4 * j)) & 15u); }
+MG_HD int blocks_W(uint32_t bl) { return blk(bl, 0) + blk(bl, 1) + blk(bl, 2) + blk(bl, 3); }
 MG_HD int tab_kbs(const TabDesc& t) { return (int)(t.info & 255); }
-MG_HD int tab_B(const TabDesc& t) { return (int)((t.info >> 8) & 255); }
-MG_HD int tab_m(const TabDesc& t) { return (int)((t.info >> 16) & 255); }
-MG_HD bool tab_bits(const TabDesc& t) { return (t.info >> 24) & 1; }
-MG_HD uint32_t tab_info(int kbs, int B, int m, bool bits) { return (uint32_t)kbs | ((uint32_t)B << 8) | ((uint32_t)m << 16) | ((uint32_t)bits << 24); }
-constexpr int MAX_SCHEMES = 6;                   // per library
-constexpr int ROUND_SCHEMES = 3;                 // per round
+MG_HD int tab_m(const TabDesc& t) { return (int)((t.info >> 8) & 15); }
+MG_HD bool tab_bits(const TabDesc& t) { return (t.info >> 12) & 1; }
+MG_HD uint32_t tab_blocks(const TabDesc& t) { return t.info >> 16; }
+MG_HD int tab_W(const TabDesc& t) { return blocks_W(tab_blocks(t)); }
+MG_HD uint32_t tab_info(int kbs, uint32_t blocks, int m, bool bits) { return (uint32_t)kbs | ((uint32_t)m << 8) | ((uint32_t)bits << 12) | (blocks << 16); }
+constexpr int MAX_SCHEMES = 8;                   // per library
+constexpr int ROUND_SCHEMES = 6;                 // per round
 // the schemes one round may use, most specific first (round_schemes)
 struct RoundSch { int32_t n; TabDesc t[ROUND_SCHEMES]; };
 struct LibDev {
@@ -101,6 +109,11 @@ struct LibDev {
     const CSlot*    cslots;
     const uint32_t* cpos;        // entries of the buckets that hold more than one
     uint32_t  lds_tw, lds_bw;    // 64-bit words of text / of the N bitmap a block stages (0: not such a library)
+    // the reference of a text position as a rank query: sep = bitmap of the separators alone (null / lds_sw = 0: the
+    // library holds no N, so `bad` is that bitmap), rank[j] = separators before bitmap word j
+    const uint64_t* sep;
+    const uint32_t* rank;
+    uint32_t  lds_sw;
 };
 constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu, SLOT_LIST = 0x7FFFFFFFu, POS_REV = 0x80000000u, POS_MASK = 0x7FFFFFFFu;
 
@@ -648,14 +661,38 @@ MG_HD int scheme_nshapes(int m) { return m == 1 ? 4 : 6; }
 // leading blocks: it finds every alignment without a mismatch in the first (4 - m) * B nt.
 MG_HD uint32_t scheme_shape(int m, int i) { return ((m == 1 ? 0xDBE7u : 0xCA6953u) >> (4 * i)) & 15u; }
 MG_HD uint32_t shape_mirror(uint32_t mask) { return ((mask & 1) << 3) | ((mask & 2) << 1) | ((mask & 4) >> 1) | ((mask & 8) >> 3); }
-// code of the blocks a shape selects from a 4B-nt window (first nt most significant), in window order
-MG_HD uint32_t shape_code(uint64_t win, int B, uint32_t mask) {
+// nt a shape selects
+MG_HD int shape_sel(uint32_t bl, uint32_t mask) {
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) n += ((mask >> j) & 1) ? blk(bl, j) : 0;
+    return n;
+}
+// code of the blocks a shape selects from a W-nt window (W = the blocks' sum; first nt most significant), in window order
+MG_HD uint32_t shape_code(uint64_t win, uint32_t bl, uint32_t mask) {
+    uint32_t code = 0;
+    int left = blocks_W(bl);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int bj = blk(bl, j);
+        left -= bj;
+        if ((mask >> j) & 1) code = (code << (2 * bj)) | (uint32_t)((win >> (2 * left)) & ones(2 * bj));
+    }
+    return code;
+}
+// the same for four equal blocks of B nt (the kernels' instantiation for rounds whose one scheme is of this kind: fixed
+// shifts instead of per-block ones -- the general form costs the one-mismatch rounds 16 B more scratch per lane)
+MG_HD uint32_t shape_code_eq(uint64_t win, int B, uint32_t mask) {
     uint32_t code = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if ((mask >> j) & 1) code = (code << (2 * B)) | (uint32_t)((win >> (2 * B * (3 - j))) & ones(2 * B));
     return code;
 }
+MG_HD bool blocks_equal(uint32_t bl) { return bl == blocks_eq(blk(bl, 0)); }
+// fewest / most nt a shape of the scheme selects (its least / most specific key)
+MG_HD int scheme_min_sel(uint32_t bl, int m) { int v = 99; for (int i = 0; i < (m == 1 ? 4 : 6); ++i) { const int x = shape_sel(bl, ((m == 1 ? 0xDBE7u : 0xCA6953u) >> (4 * i)) & 15u); v = x < v ? x : v; } return v; }
+MG_HD int scheme_max_sel(uint32_t bl, int m) { int v = 0; for (int i = 0; i < (m == 1 ? 4 : 6); ++i) { const int x = shape_sel(bl, ((m == 1 ? 0xDBE7u : 0xCA6953u) >> (4 * i)) & 15u); v = x > v ? x : v; } return v; }
 // up to 32 nt of text starting at p, first nt most significant
 MG_HD uint64_t text_window(const uint64_t* __restrict__ text, uint32_t p, int k) {
     uint32_t wi = p >> 5; int bs = (p & 31) * 2;
@@ -664,18 +701,21 @@ MG_HD uint64_t text_window(const uint64_t* __restrict__ text, uint32_t p, int k)
     v &= ones(2 * k);
     return rev2(v) >> (64 - 2 * k);
 }
+// reverse complement of a k-nt code of up to 32 nt
+MG_HD uint64_t rc_code64(uint64_t x, int k) { return ((~rev2(x)) >> (64 - 2 * k)) & ones(2 * k); }
 // The two buckets of text position p in a both-strand table: bf holds (p, fwd), br holds (p, rev).
-//   contiguous table (B = 0): k-mer K -> K, rc(K).
+//   contiguous table (bl = 0): k-mer K -> K, rc(K).
 //   shape table: a forward alignment puts the read window on the text window W as it is: key = code of the shape's
-//   blocks in W.  A reverse alignment puts the reverse complement of the read window there, which mirrors the block
-//   order: the read's code is then the reverse complement of W's code under the MIRRORED shape.
-// k = nt of the key that index the table (its leading nt); sel = nt the shape selects.
-MG_HD void both_buckets(const uint64_t* __restrict__ text, uint32_t p, int k, int B, uint32_t mask, uint32_t& bf, uint32_t& br) {
-    if (B == 0) { bf = text_kmer(text, p, k); br = rc_code(bf, k); return; }
-    const uint64_t win = text_window(text, p, 4 * B);
-    const int sel = B * __builtin_popcount(mask);
-    bf = shape_code(win, B, mask) >> (2 * (sel - k));
-    br = rc_code(shape_code(win, B, shape_mirror(mask)), sel) >> (2 * (sel - k));
+//   blocks in W.  A reverse alignment puts the reverse complement of the read window there, i.e. the read window IS
+//   the reverse complement of W: key = code of the shape's blocks in rc(W).
+// k = most nt of a key that index the table (the key's leading nt).
+MG_HD void both_buckets(const uint64_t* __restrict__ text, uint32_t p, int k, uint32_t bl, uint32_t mask, uint32_t& bf, uint32_t& br) {
+    if (bl == 0) { bf = text_kmer(text, p, k); br = rc_code(bf, k); return; }
+    const int W = blocks_W(bl);
+    const uint64_t win = text_window(text, p, W);
+    const int sel = shape_sel(bl, mask), kk = sel < k ? sel : k;
+    bf = shape_code(win, bl, mask) >> (2 * (sel - kk));
+    br = shape_code(rc_code64(win, W), bl, mask) >> (2 * (sel - kk));
 }
 __global__ void __launch_bounds__(256)
 k_kmer_hist(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* hist) {
@@ -683,7 +723,7 @@ k_kmer_hist(const uint64_t* __restrict__ text, uint32_t T, int kb, uint32_t* his
     if (p < T) atomicAdd(&hist[text_kmer(text, p, kb)], 1u);
 }
 __global__ void __launch_bounds__(256)
-k_both_hist(const uint64_t* __restrict__ text, uint32_t T, int k, int B, uint32_t mask, uint32_t* hist) {
+k_both_hist(const uint64_t* __restrict__ text, uint32_t T, int k, uint32_t B, uint32_t mask, uint32_t* hist) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < T) { uint32_t bf, br; both_buckets(text, p, k, B, mask, bf, br); atomicAdd(&hist[bf], 1u); atomicAdd(&hist[br], 1u); }
 }
@@ -768,10 +808,10 @@ MG_HD PEnt make_pent(const LibDev& L, uint32_t p, int K, bool rev) {
     return e;
 }
 __global__ void __launch_bounds__(256)
-k_both_scatter(LibDev L, int k, int B, uint32_t mask, uint32_t* cursor, PEnt* pent) {
+k_both_scatter(LibDev L, int k, uint32_t B, uint32_t mask, uint32_t* cursor, PEnt* pent) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < L.T) {
-        const int K = B ? 4 * B : k;
+        const int K = B ? blocks_W(B) : k;
         uint32_t bf, br; both_buckets(L.text, p, k, B, mask, bf, br);
         uint32_t at = atomicAdd(&cursor[bf], 1u);
         pent[at] = make_pent(L, p, K, false);
@@ -810,7 +850,7 @@ k_slot_fill(const uint32_t* __restrict__ off, const PEnt* __restrict__ pent, uin
 
 // the same two steps for a compact table: entries are text position | strand, a slot is the bucket's range or its only entry
 __global__ void __launch_bounds__(256)
-k_both_scatter_pos(const uint64_t* __restrict__ text, uint32_t T, int k, int B, uint32_t mask, uint32_t* cursor, uint32_t* __restrict__ cpos) {
+k_both_scatter_pos(const uint64_t* __restrict__ text, uint32_t T, int k, uint32_t B, uint32_t mask, uint32_t* cursor, uint32_t* __restrict__ cpos) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < T) {
         uint32_t bf, br; both_buckets(text, p, k, B, mask, bf, br);
@@ -1187,7 +1227,7 @@ MG_HD bool probe_round(const LibDev& L, const RoundDev& P) { return L.slots != n
 // The schemes a round may use: those that cover the mismatches allowed inside the seed, min(seedmm, maxmm) -- and,
 // where a scheme window can reach beyond a short seed, those that cover the whole-read allowance maxmm -- most
 // specific first, at most ROUND_SCHEMES.
-MG_HD int scheme_rank(const TabDesc& t) { return (4 - tab_m(t)) * tab_B(t) * 8 - tab_m(t); }
+MG_HD int scheme_rank(const TabDesc& t) { return scheme_min_sel(tab_blocks(t), tab_m(t)) * 64 + tab_W(t); }      // by its least specific key, then by its window
 MG_HD RoundSch round_schemes(const LibDev& L, const RoundDev& P) {
     RoundSch RS; RS.n = 0;
     const int ms = P.seedmm < P.maxmm ? P.seedmm : P.maxmm;
@@ -1257,26 +1297,35 @@ MG_HD void probe_setup(const uint64_t* key, const LibDev& L, const RoundDev& P, 
     bool found = false;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        const int B = tab_B(RS.t[j]), m = tab_m(RS.t[j]);
-        const bool fits = !found && j < RS.n && 4 * B <= Q.l && m >= (4 * B <= Q.s ? ms : P.maxmm);
+        const int W = tab_W(RS.t[j]), m = tab_m(RS.t[j]);
+        const bool fits = !found && j < RS.n && W <= Q.l && m >= (W <= Q.s ? ms : P.maxmm);
         if (fits) { R.tab = RS.t[j]; found = true; }
     }
     if (!found) return;
     R.nlook = scheme_nshapes(tab_m(R.tab)); R.served = true;
-    R.lead = (4 - tab_m(R.tab)) * tab_B(R.tab) <= Q.s;
+    R.lead = shape_sel(tab_blocks(R.tab), scheme_shape(tab_m(R.tab), 0)) <= Q.s;
 }
 // lookup i (< R.nlook): slot index, occupancy bit index (used if tab_bits(R.tab)), and where the looked-up window
 // starts in the read (ps; a scheme's window starts the read)
+template <bool EQ = false>
 MG_HD void probe_lookup(const ProbeRead& R, const LibDev& L, int i, uint32_t& slot, uint32_t& b, int& ps) {
-    const int B = tab_B(R.tab), kbs = tab_kbs(R.tab);
-    if (B == 0) {
+    const uint32_t bl = tab_blocks(R.tab); const int kbs = tab_kbs(R.tab);
+    if (bl == 0) {
         Oriented<2> o; o.s[0] = R.r[0]; o.s[1] = R.r[1]; o.n[0] = 0; o.l = R.l;
         ps = i == 0 ? R.ps[0] : (i == 1 ? R.ps[1] : R.ps[2]);
         b = kmer_code<2>(o, ps, L.kb);
     } else {
-        const int m = tab_m(R.tab), sel = (4 - m) * B;
-        const uint64_t win = rev2(R.r[0] & ones(8 * B)) >> (64 - 8 * B);   // first 4B nt of the read, first nt most significant
-        b = shape_code(win, B, scheme_shape(m, i)) >> (2 * (sel - kbs));
+        const int m = tab_m(R.tab);
+        const uint32_t mask = scheme_shape(m, i);
+        if (EQ) {
+            const int B = blk(bl, 0), sel = (4 - m) * B;
+            const uint64_t win = rev2(R.r[0] & ones(8 * B)) >> (64 - 8 * B);
+            b = shape_code_eq(win, B, mask) >> (2 * (sel - kbs));          // (kbs = min(sel, kb))
+        } else {
+            const int W = blocks_W(bl), sel = shape_sel(bl, mask), kk = sel < kbs ? sel : kbs;
+            const uint64_t win = rev2(R.r[0] & ones(2 * W)) >> (64 - 2 * W);   // first W nt of the read, first nt most significant
+            b = shape_code(win, bl, mask) >> (2 * (sel - kk));
+        }
         ps = 0;
         b += (uint32_t)i << (2 * kbs);                                     // shape i's table
     }
@@ -1287,7 +1336,7 @@ MG_HD void probe_lookup(const ProbeRead& R, const LibDev& L, int i, uint32_t& sl
 // every stratum-0 alignment.  Plain pieces: piece_needed's rule.
 MG_HD bool probe_needed(const ProbeRead& R, const RoundDev& P, int i, uint64_t score) {
     if (i == 0 || score == 0) return true;
-    if (tab_B(R.tab)) return !(R.lead && (score >> 36) == 4);
+    if (tab_blocks(R.tab)) return !(R.lead && (score >> 36) == 4);
     return piece_needed(P, i, score);
 }
 // One entry against a read whose lookup started ps nt into it: false = no alignment, true = valid alignment (f, sm,
@@ -1337,7 +1386,7 @@ MG_HD void probe_record(ProbeBest& Bst, int sm, int tm, uint32_t w, int f, uint3
     if (x > Bst.score) { Bst.score = x; Bst.ref = ref; }
     Bst.rmax = y > Bst.rmax ? y : Bst.rmax; Bst.rmin = z > Bst.rmin ? z : Bst.rmin;
 }
-MG_HD int tab_K(const TabDesc& t, const LibDev& L) { return tab_B(t) ? 4 * tab_B(t) : L.kb; }
+MG_HD int tab_K(const TabDesc& t, const LibDev& L) { return tab_blocks(t) ? tab_W(t) : L.kb; }
 
 // Serial form of the probe path for one read: false = not served (ask the generic matcher).
 __host__ __device__ inline bool probe_one(const uint64_t* key, const LibDev& L, const RoundDev& P, ProbeBest& Bst) {
@@ -1663,7 +1712,8 @@ __device__ __forceinline__ void finish_on_text(const uint64_t* __restrict__ ukey
 #ifndef MG_PF
 #define MG_PF 2                                  // queue entries a wave has in flight in phase 2 (4 spills registers: slower)
 #endif
-// one block's worth (MB reads, block number bid of the launch's work) of a round
+template <int KW> struct MatchTile { static constexpr uint32_t N = KW == 2 ? 256u : 64u; };       // reads per block (match_block)
+// one block's worth (MatchTile reads, block number bid of the launch's work) of a round
 template <int KW, int RN>
 __device__ __forceinline__ void match_block(const uint32_t bid, const uint32_t n, const uint64_t* __restrict__ ukeys, uint8_t* ann_round, int32_t* ann_ref,
               uint8_t* ann_amb, const LibDev& L, const RoundDev& P, int thr, unsigned long long* stats,
@@ -1678,8 +1728,13 @@ __device__ __forceinline__ void match_block(const uint32_t bid, const uint32_t n
     __shared__ uint32_t s_u[MB];
     __shared__ uint32_t s_qn, s_next, s_wcnt[MB / 64], s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t i = bid * MB + tid;
-    const uint32_t u = i < n ? (list ? list[i] : i) : EMPTY;
+    // MT reads per block: the block's 256 threads for the 16-byte class; 64 for the 48-byte class -- its tables hold a few
+    // ten thousand uniques (reads with N), which as 256-read tiles were ~150 blocks on a 256-CU chip, each a long serial
+    // chain of phase 1 -> drain -> results (0.84 ms for 40 K uniques in the two-mismatch round); four times the blocks,
+    // each draining a quarter of the lists with all of its waves
+    constexpr uint32_t MT = MatchTile<KW>::N;
+    const uint32_t i = bid * MT + tid;
+    const uint32_t u = (tid < MT && i < n) ? (list ? list[i] : i) : EMPTY;
     s_u[tid] = u;
     bool active = false;
     uint64_t k[KW];
@@ -1873,24 +1928,25 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     // earlier launches of this kernel left of the reads the probe kernel had handed them).  Survivors go to ONE dense list.
     if (U_dev) { const uint32_t ud = U0 + (uint32_t)(*U_dev >> 32); U = ud < U ? ud : U; }      // never beyond the bound the launch and its buffers were sized for
     if (in.K > 1) {
-        const uint32_t per = in.cap / MB;                  // tiles a sub-list can hold (cap is a multiple of the block size)
+        constexpr uint32_t MT = MatchTile<KW>::N;
+        const uint32_t per = in.cap / MT;                  // tiles a sub-list can hold (cap is a multiple of the block size)
         for (uint32_t t = blockIdx.x; t < in.K * per; t += gridDim.x) {
             const uint32_t k = t % in.K, j = t / in.K;
             const uint32_t nk = (uint32_t)in.n[(size_t)k * LIST_NSTRIDE];
-            if ((uint64_t)j * MB >= nk) continue;
+            if ((uint64_t)j * MT >= nk) continue;
             match_block<KW, RN>(j, nk, ukeys, ann_round, ann_ref, ann_amb, L, P, thr, stats, in.p + (size_t)k * in.cap, next_list, next_n, init);
             __syncthreads();                               // the block's LDS state is reused by its next piece of work
         }
     } else {
         const uint32_t n = (in.p && in.n) ? (uint32_t)*in.n : U;          // (a list without a length word is as long as the table: EMPTY = a hole)
-        for (uint32_t bid = blockIdx.x; (uint64_t)bid * MB < n; bid += gridDim.x) {
+        for (uint32_t bid = blockIdx.x; (uint64_t)bid * MatchTile<KW>::N < n; bid += gridDim.x) {
             match_block<KW, RN>(bid, n, ukeys, ann_round, ann_ref, ann_amb, L, P, thr, stats, in.p, next_list, next_n, init);
             __syncthreads();
         }
     }
     if (list2) {
         const uint32_t n2 = (uint32_t)*list2_n;
-        for (uint32_t bid = blockIdx.x; (uint64_t)bid * MB < n2; bid += gridDim.x) {
+        for (uint32_t bid = blockIdx.x; (uint64_t)bid * MatchTile<KW>::N < n2; bid += gridDim.x) {
             match_block<KW, RN>(bid, n2, ukeys, ann_round, ann_ref, ann_amb, L, P, thr, stats, list2, next_list, next_n, false);
             __syncthreads();
         }
@@ -1917,7 +1973,7 @@ template <int NS> struct ProbeQ { static constexpr int Q4 = NS >= 3 ? 768 : 320,
 #define MG_PROBE_WAVES 7                        // the scheme-carrying instantiations: 72 registers and 8-12 B of scratch (6 waves: none; 8: round 3 0.99 ms)
 #endif
 #ifndef MG_PROBE_WAVES3
-#define MG_PROBE_WAVES3 MG_PROBE_WAVES
+#define MG_PROBE_WAVES3 6                       // several schemes, of unequal blocks (the two-mismatch round): 56 B of scratch at 7 waves, none at 6 -- round 5 0.47 -> 0.40 ms
 #endif
 #ifndef MG_PROBE_WAVES0
 #define MG_PROBE_WAVES0 8                       // the scheme-free instantiation (rounds 1 and 4 of the reference cascade) fits 64 registers but for 16 B of scratch
@@ -2031,7 +2087,7 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         for (int j = 0; j < PW; ++j) {
             have[j] = run && !fb && i0 + j < R.nlook && probe_needed(R, P, i0 + j, Bst.score);
             slot[j] = 0; b[j] = 0; ps[j] = 0;
-            if (have[j]) probe_lookup(R, L, i0 + j, slot[j], b[j], ps[j]);
+            if (have[j]) probe_lookup<NS == 1>(R, L, i0 + j, slot[j], b[j], ps[j]);
             any = any || have[j];
         }
         if (i0 && !__any(any)) break;
@@ -2149,13 +2205,27 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
 //   * Results meet the owner through LDS atomic max on the three order keys of the generic matcher (positions).
 // What the path cannot serve (no fitting scheme, a bucket of more than LDS_MAX_LIST entries) goes on the `fb` list for
 // the generic kernel, as on the probe path.  Lists in / out as k_probe_round (a tile here is 64 reads).
-constexpr int LDS_BLOCK = 512, LDS_WAVES = LDS_BLOCK / 64;
+
 constexpr int LDS_SHORT = 16;                    // entries of a "short" list
 constexpr int LDS_SQ = 128, LDS_LQ = 64;         // queue capacities per wave (each holds at least one lookup step's lists: 64)
+#ifndef MG_LDS_LB
+#define MG_LDS_LB 8
+#endif
+#ifndef MG_LDS_SB
+#define MG_LDS_SB 4
+#endif
+constexpr int LDS_LB = MG_LDS_LB, LDS_SB = MG_LDS_SB;      // long lists / short-queue steps whose entries a drain has in flight at once
+// The three order keys of an alignment in 32 bits each (text positions of such a library fit 24 bits): same order as
+// hit_score / hit_kmax / hit_kmin.
+MG_HD uint32_t sc32(int sm, int tm, uint32_t w, int f) { return ((uint32_t)(4 - sm) << 28) | ((uint32_t)tm << 26) | (w << 1) | (uint32_t)f; }
+MG_HD uint32_t kx32(int sm, uint32_t w) { return ((uint32_t)(4 - sm) << 28) | w; }
+MG_HD uint32_t kn32(int sm, uint32_t w) { return ((uint32_t)(4 - sm) << 28) | (0xFFFFFFu - w); }
+MG_HD uint64_t sc32_as_score(uint32_t x) { return x ? ((uint64_t)(x >> 28) << 36) | 1ull : 0ull; }      // what probe_needed looks at: the stratum
 struct LdsWave {
-    unsigned long long best[3][64];              // score / kmax / kmin of what the drains found, per owner lane
-    uint64_t r0[64], r1[64], c0[64], c1[64];     // the lanes' reads and their reverse complements
+    uint32_t best[3][64];                        // score / kmax / kmin of what the drains found, per owner lane
+    uint64_t r0[64], r1[64];                     // the lanes' reads
     uint32_t ls[64];                             // l | s << 8
+    uint32_t cl[64];                             // first 16 nt of their reverse complements (the drains' pre-filter)
     uint64_t sq[LDS_SQ], lq[LDS_LQ];             // list descriptors: lo (0-23) | n (24-39) | owner (40-45) | ps (46-51) | K (52-57)
 };
 MG_HD uint64_t lds_desc(uint32_t lo, uint32_t n, uint32_t owner, int ps, int K) {
@@ -2168,39 +2238,114 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+// The drains' pre-filter: the first min(l, 16) nt of the alignment an entry stands for -- one 8-byte LDS read, a funnel
+// shift, XOR and a popcount, ~15 vector instructions.  Nearly every entry of a short-key bucket fails here (a 6-nt bucket
+// of the miRNA library holds ~36 entries, of which ~0.04 % pass); the full check (pos_verify, ~10x the instructions) runs
+// for the others only.  off_f / off_r = where the looked-up window starts in the read / in its reverse complement;
+// q_f / q_r = the first 16 nt of either; m32 = mask of min(l, 16) nt.
+__device__ __forceinline__ bool lds_prefilter(const uint32_t* text32, uint32_t T, uint32_t e, int l, int off_f, int off_r,
+                                              uint32_t q_f, uint32_t q_r, uint32_t m32, int maxmm) {
+    const bool f = !(e >> 31);
+    const int w = (int)(e & POS_MASK) - (f ? off_f : off_r);
+    const bool ok = w >= 0 && (uint32_t)(w + l) <= T;
+    const uint32_t wc = ok ? (uint32_t)w : 0u;
+    const uint32_t lo = text32[wc >> 4], hi = text32[(wc >> 4) + 1];
+    const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, (wc & 15) * 2);
+    uint32_t d = x ^ (f ? q_f : q_r);
+    d = (d | (d >> 1)) & m32;
+    return ok && __popc(d) <= maxmm;
+}
+MG_HD uint32_t lds_m32(int l) { return l >= 16 ? 0x55555555u : (((1u << (2 * l)) - 1u) & 0x55555555u); }
+// pos_verify for an entry that passed the pre-filter (bounds checked there), with the read's masks at hand: ml = its l
+// nt, sd = its seed nt in the entry's orientation (both one bit per nt)
+__device__ __forceinline__ bool pos_verify_fast(const RoundDev& P, const uint64_t* text, const uint64_t* bad, uint64_t q0, uint64_t q1,
+                                                uint64_t ml0, uint64_t ml1, uint64_t sd0, uint64_t sd1, int l, uint32_t w, int& sm, int& tm) {
+    const uint32_t wi = w >> 5; const int bs = (int)(w & 31) * 2;
+    const uint64_t t0 = text[wi], t1 = text[wi + 1], t2 = text[wi + 2];
+    const uint64_t x0 = bs ? (t0 >> bs) | (t1 << (64 - bs)) : t0, x1 = bs ? (t1 >> bs) | (t2 << (64 - bs)) : t1;
+    uint64_t d0 = x0 ^ q0, d1 = x1 ^ q1;
+    d0 = (d0 | (d0 >> 1)) & ml0; d1 = (d1 | (d1 >> 1)) & ml1;
+    tm = popc64(d0) + popc64(d1);
+    sm = popc64(d0 & sd0) + popc64(d1 & sd1);
+    const uint32_t bi = w >> 6; const int sh = (int)(w & 63);
+    const uint64_t b0 = bad[bi], b1 = bad[bi + 1];
+    const uint64_t rb = sh ? (b0 >> sh) | (b1 << (64 - sh)) : b0;
+    return tm <= P.maxmm && sm <= P.seedmm && (rb & ((1ull << l) - 1)) == 0;       // (l <= 56)
+}
 #ifndef MG_LDS_WAVES
 #define MG_LDS_WAVES 4
 #endif
+__device__ __forceinline__ uint64_t uni64(uint64_t x) { return (uint64_t)uni((uint32_t)x) | ((uint64_t)uni((uint32_t)(x >> 32)) << 32); }
+// rounds without block schemes (the exact-match round) need fewer registers: 12 waves per block, two blocks per CU
+template <int NS> struct LdsCfg { static constexpr int BLOCK = 512, WAVES = BLOCK / 64, PER_SIMD = MG_LDS_WAVES; };
 template <int RN, int NS>
-__global__ void __launch_bounds__(LDS_BLOCK, MG_LDS_WAVES)
+__global__ void __launch_bounds__(LdsCfg<NS>::BLOCK, LdsCfg<NS>::PER_SIMD)
 k_lds_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb,
             LibDev L, RoundDev P, RoundSch RS, unsigned long long* stats,
             ListIn in, ListOut out, uint32_t* fb_list, unsigned long long* fb_n, bool init,
             const unsigned long long* __restrict__ U_dev, uint32_t U0) {
+    constexpr int BLK = LdsCfg<NS>::BLOCK, NWV = LdsCfg<NS>::WAVES;
     constexpr int NL = NS == 0 ? 3 : PROBE_MAX_LOOK;                // lookups a read can have: pieces / a scheme's shapes
+    // LDS: [text | N + boundary bitmap | boundary bitmap, if the library holds N | boundaries before each bitmap word | waves]
     extern __shared__ uint64_t lds_dyn[];
     uint64_t* const s_text = lds_dyn;
-    uint64_t* const s_bad = lds_dyn + L.lds_tw;
-    LdsWave* const waves = reinterpret_cast<LdsWave*>(lds_dyn + L.lds_tw + L.lds_bw);
+    uint64_t* const s_bad = s_text + L.lds_tw;
+    uint64_t* const s_sep = L.lds_sw ? s_bad + L.lds_bw : s_bad;
+    uint32_t* const s_rank = reinterpret_cast<uint32_t*>(s_bad + L.lds_bw + L.lds_sw);
+    LdsWave* const waves = reinterpret_cast<LdsWave*>(s_bad + L.lds_bw + L.lds_sw + (L.lds_bw + 1) / 2);
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    for (uint32_t j = tid; j < L.lds_tw; j += LDS_BLOCK) s_text[j] = L.text[j];
-    for (uint32_t j = tid; j < L.lds_bw; j += LDS_BLOCK) s_bad[j] = L.bad[j];
+    for (uint32_t j = tid; j < L.lds_tw; j += BLK) s_text[j] = L.text[j];
+    for (uint32_t j = tid; j < L.lds_bw; j += BLK) { s_bad[j] = L.bad[j]; s_rank[j] = L.rank[j]; }
+    for (uint32_t j = tid; j < L.lds_sw; j += BLK) s_sep[j] = L.sep[j];
     __syncthreads();
     if (U_dev) { const uint32_t ud = U0 + (uint32_t)(*U_dev >> 32); U = ud < U ? ud : U; }      // as in k_match_round; never beyond what the launch was sized for
     LdsWave& W = waves[tid >> 6];
-    const uint32_t gw = blockIdx.x * LDS_WAVES + (tid >> 6), nw = gridDim.x * LDS_WAVES;
+    const uint32_t gw = blockIdx.x * NWV + (tid >> 6), nw = gridDim.x * NWV;
     const uint32_t ndense = (in.p && in.n) ? (uint32_t)*in.n : U;
     const uint32_t ntiles = in.K > 1 ? in.K * (in.cap / 64) : (ndense + 63) / 64;
     const unsigned long long below = (1ull << lane) - 1;
-    uint32_t n_act = 0, n_hit = 0;                                  // wave totals, flushed once
-    for (uint32_t t = gw; t < ntiles; t += nw) {
-        const uint32_t* __restrict__ list = in.p;
-        uint32_t n, i0;
+    // the reference that holds text position w: the boundaries (separators) before it, from the bitmap in LDS
+    auto ref_at = [&](uint32_t w) -> uint32_t { return s_rank[w >> 6] + (uint32_t)__popcll(s_sep[w >> 6] & ones((int)(w & 63))); };
+    // tile t of the launch's work: its list, that list's length, the tile's first element; false = nothing there
+    auto tile_of = [&](uint32_t t, const uint32_t*& list, uint32_t& n, uint32_t& i0) -> bool {
+        list = in.p;
         if (in.K > 1) {
             const uint32_t sk = t % in.K;
             n = (uint32_t)in.n[(size_t)sk * LIST_NSTRIDE]; i0 = (t / in.K) * 64; list += (size_t)sk * in.cap;
         } else { n = ndense; i0 = t * 64; }
-        if (i0 >= n) continue;
+        return i0 < n;
+    };
+    auto next_tile = [&](uint32_t t) -> uint32_t {                  // first tile >= t of this wave's stride that holds anything
+        const uint32_t* l_; uint32_t n_, i_;
+        while (t < ntiles && !tile_of(t, l_, n_, i_)) t += nw;
+        return t;
+    };
+    uint32_t n_act = 0, n_hit = 0;                                  // wave totals, flushed once
+    // the NEXT tile's unique ids and keys are fetched while this one is worked on
+    uint32_t t = next_tile(gw);
+    uint32_t u = EMPTY; uint64_t k[2] = {0, 0}; uint8_t done_before = 0; bool from_list = false;
+    if (t < ntiles) {
+        const uint32_t* list; uint32_t n, i0;
+        tile_of(t, list, n, i0);
+        const uint32_t i = i0 + lane;
+        from_list = list != nullptr;
+        u = i < n ? (list ? list[i] : i) : EMPTY;
+        if (u != EMPTY) {
+            if (!init && !list) done_before = ann_round[u];
+            k[0] = ukeys[(uint64_t)u * 2]; k[1] = ukeys[(uint64_t)u * 2 + 1];
+        }
+    }
+    while (t < ntiles) {
+        const uint32_t tn = next_tile(t + nw);
+        uint32_t un = EMPTY; bool nlist = false;
+        if (tn < ntiles) {
+            const uint32_t* list; uint32_t n, i0;
+            tile_of(tn, list, n, i0);
+            const uint32_t i = i0 + lane;
+            nlist = list != nullptr;
+            un = i < n ? (list ? list[i] : i) : EMPTY;
+        }
         uint32_t* next_list = out.p;
         unsigned long long* next_n = out.n;
         uint32_t next_cap = 0xFFFFFFFFu;
@@ -2208,33 +2353,25 @@ k_lds_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, 
             const uint32_t ok = t % out.K;
             next_list += (size_t)ok * out.cap; next_n += (size_t)ok * LIST_NSTRIDE; next_cap = out.cap;
         }
-        const uint32_t i = i0 + lane;
-        const uint32_t u = i < n ? (list ? list[i] : i) : EMPTY;
-        uint64_t k[2] = {0, 0};
-        uint8_t done_before = 0;
-        if (u != EMPTY) {
-            if (init) { ann_round[u] = 0; ann_ref[u] = -1; ann_amb[u] = 0; }       // as in k_match_round
-            else if (!list) done_before = ann_round[u];
-            k[0] = ukeys[(uint64_t)u * 2]; k[1] = ukeys[(uint64_t)u * 2 + 1];
-        }
+        if (u != EMPTY && init) { ann_round[u] = 0; ann_ref[u] = -1; ann_amb[u] = 0; }       // as in k_match_round
         const bool listed = u != EMPTY && done_before == 0;
         bool active = false;
         if (listed) {
             const int len = key_len<2>(k);
             active = !(P.len_lt && !(len < P.len_lt)) && !(P.len_gt && !(len > P.len_gt));
         }
-        if (!__any(active) && !next_list) continue;
         if (!active) { k[0] = 0; k[1] = 0; }
         ProbeRead R;
         probe_setup<NS>(k, L, P, RS, R);
         R.ok = R.ok && active;
         const bool run = R.ok && R.served;
         bool fb = R.ok && !R.served;
-        uint64_t c0, c1;
-        revcomp2(R.r[0], R.r[1], R.l, c0, c1);
         W.best[0][lane] = 0; W.best[1][lane] = 0; W.best[2][lane] = 0;
-        W.r0[lane] = R.r[0]; W.r1[lane] = R.r[1]; W.c0[lane] = c0; W.c1[lane] = c1;
+        W.r0[lane] = R.r[0]; W.r1[lane] = R.r[1];
         W.ls[lane] = (uint32_t)(R.l & 255) | ((uint32_t)(R.s & 255) << 8);
+        uint64_t c0 = 0, c1 = 0;
+        revcomp2(R.r[0], R.r[1], R.l, c0, c1);
+        W.cl[lane] = (uint32_t)c0;
         const int K = tab_K(R.tab, L);
         const bool ubits = tab_bits(R.tab);
         // every lookup of the read: occupancy words first, then the slots, all in flight at once
@@ -2243,11 +2380,17 @@ k_lds_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, 
         for (int j = 0; j < NL; ++j) {
             have[j] = run && j < R.nlook;
             slot[j] = 0; bb[j] = 0; ps[j] = 0;
-            if (have[j]) probe_lookup(R, L, j, slot[j], bb[j], ps[j]);
+            if (have[j]) probe_lookup<NS == 1>(R, L, j, slot[j], bb[j], ps[j]);
         }
         uint32_t wd[NL];
 #pragma unroll
         for (int j = 0; j < NL; ++j) wd[j] = (have[j] && ubits) ? L.sbits[bb[j] >> 5] : 0xFFFFFFFFu;
+        // (the next tile's keys: its ids have been on their way since the top of the loop)
+        uint64_t kn[2] = {0, 0}; uint8_t done_n = 0;
+        if (un != EMPTY) {
+            if (!init && !nlist) done_n = ann_round[un];
+            kn[0] = ukeys[(uint64_t)un * 2]; kn[1] = ukeys[(uint64_t)un * 2 + 1];
+        }
 #pragma unroll
         for (int j = 0; j < NL; ++j) have[j] = have[j] && ((wd[j] >> (bb[j] & 31)) & 1);
         CSlot sl[NL];
@@ -2255,43 +2398,107 @@ k_lds_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, 
         for (int j = 0; j < NL; ++j) { sl[j] = CSlot{0, 0}; if (have[j]) sl[j] = L.cslots[slot[j]]; }
         wave_lds_sync();
 
-        PosBest Bst; Bst.score = 0; Bst.kmax = 0; Bst.kmin = 0;     // what this lane finds itself (single-entry buckets)
+        uint32_t b_sc = 0, b_kx = 0, b_kn = 0;                      // what this lane finds itself (single-entry buckets): sc32 / kx32 / kn32
         uint32_t sq_n = 0, lq_n = 0;                                // wave-uniform
-        auto judge = [&](uint32_t e, uint32_t owner, int kk, int pss) {
-            const bool rev = e >> 31;
-            const uint64_t q0 = rev ? W.c0[owner] : W.r0[owner], q1 = rev ? W.c1[owner] : W.r1[owner];
-            const uint32_t ls = W.ls[owner];
-            int f, sm, tm; uint32_t w;
-            if (pos_verify(P, s_text, s_bad, L.T, q0, q1, (int)(ls & 255), (int)(ls >> 8), kk, pss, e, f, sm, tm, w)) {
-                atomicMax(&W.best[0][owner], (unsigned long long)hit_score(sm, tm, w, f));
-                atomicMax(&W.best[1][owner], (unsigned long long)hit_kmax(sm, w));
-                atomicMax(&W.best[2][owner], (unsigned long long)hit_kmin(sm, w));
-            }
+        // one list entry against its owner's read (from LDS; the reverse complement is made here, for reverse entries)
+        const uint32_t* const s_text32 = reinterpret_cast<const uint32_t*>(s_text);
+        // an entry that passed the pre-filter, against its owner's read (from LDS; masks and reverse complement made here)
+        auto record = [&](uint32_t owner, int sm, int tm, uint32_t w, int f) {
+            atomicMax(&W.best[0][owner], sc32(sm, tm, w, f)); atomicMax(&W.best[1][owner], kx32(sm, w)); atomicMax(&W.best[2][owner], kn32(sm, w));
         };
+        auto judge = [&](uint32_t e, uint32_t owner, int kk, int pss) {
+            uint64_t q0 = W.r0[owner], q1 = W.r1[owner];
+            const uint32_t ls = W.ls[owner];
+            const int l = (int)(ls & 255), sd = (int)(ls >> 8);
+            const bool rev = e >> 31;
+            if (rev) { const uint64_t a0 = q0, a1 = q1; revcomp2(a0, a1, l, q0, q1); }
+            const int sa = rev ? l - sd : 0, sb = rev ? l : sd;
+            const uint32_t w = (e & POS_MASK) - (uint32_t)(rev ? l - pss - kk : pss);
+            int sm, tm;
+            if (pos_verify_fast(P, s_text, s_bad, q0, q1, ones(2 * l) & M55, ones(2 * l - 64) & M55, (ones(2 * sb) ^ ones(2 * sa)) & M55,
+                                (ones(2 * sb - 64) ^ ones(2 * sa - 64)) & M55, l, w, sm, tm)) record(owner, sm, tm, w, rev ? 0 : 1);
+        };
+        // Both drains fetch the entries of several steps before they judge any: a list entry comes from the L2 or the
+        // Infinity Cache (~1-2 us under load), and a drain that waited for each step's entries in turn ran at that pace.
         auto drain_short = [&]() {
             wave_lds_sync();
             constexpr int PER = 64 / LDS_SHORT;
-            for (uint32_t base = 0; base < sq_n; base += PER) {
-                const uint32_t q = base + lane / LDS_SHORT, ei = lane % LDS_SHORT;
-                const uint64_t d = q < sq_n ? W.sq[q] : 0ull;
-                if (ei < (uint32_t)((d >> 24) & 0xFFFF)) judge(L.cpos[(uint32_t)(d & 0xFFFFFF) + ei], (uint32_t)(d >> 40) & 63, (int)(d >> 52) & 63, (int)(d >> 46) & 63);
+            const uint32_t ql = lane / LDS_SHORT, ei = lane % LDS_SHORT;
+            for (uint32_t base = 0; base < sq_n; base += PER * LDS_SB) {
+                uint32_t e[LDS_SB];
+#pragma unroll
+                for (int j = 0; j < LDS_SB; ++j) {
+                    const uint32_t q = base + j * PER + ql;
+                    const uint64_t d = q < sq_n ? W.sq[q] : 0ull;
+                    e[j] = ei < (uint32_t)((d >> 24) & 0xFFFF) ? L.cpos[(uint32_t)(d & 0xFFFFFF) + ei] : 0u;
+                }
+#pragma unroll 1
+                for (int j = 0; j < LDS_SB; ++j) {
+                    const uint32_t q = base + j * PER + ql;
+                    const uint32_t e0 = e[0];
+#pragma unroll
+                    for (int x = 0; x + 1 < LDS_SB; ++x) e[x] = e[x + 1];
+                    if (base + j * PER >= sq_n) break;
+                    const uint64_t d = q < sq_n ? W.sq[q] : 0ull;
+                    if (ei < (uint32_t)((d >> 24) & 0xFFFF)) {
+                        const uint32_t owner = (uint32_t)(d >> 40) & 63; const int kk = (int)(d >> 52) & 63, pss = (int)(d >> 46) & 63;
+                        const int l = (int)(W.ls[owner] & 255);
+                        if (lds_prefilter(s_text32, L.T, e0, l, pss, l - pss - kk, (uint32_t)W.r0[owner], W.cl[owner], lds_m32(l), P.maxmm)) judge(e0, owner, kk, pss);
+                    }
+                }
             }
             sq_n = 0;
             wave_lds_sync();
         };
         auto drain_long = [&]() {
             wave_lds_sync();
-            for (uint32_t q = 0; q < lq_n; ++q) {
-                const uint64_t d = W.lq[q];
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(d & 0xFFFFFF));
-                const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((d >> 24) & 0xFFFF));
-                const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(d >> 40));      // owner | ps << 6 | K << 12
-                for (uint32_t c = 0; c < cnt; c += 64)
-                    if (c + lane < cnt) judge(L.cpos[lo + c + lane], meta & 63, (int)(meta >> 12) & 63, (int)(meta >> 6) & 63);
+            for (uint32_t q0 = 0; q0 < lq_n; q0 += LDS_LB) {
+                uint32_t e[LDS_LB];
+#pragma unroll
+                for (int j = 0; j < LDS_LB; ++j) {
+                    const uint64_t d = W.lq[q0 + j < lq_n ? q0 + j : lq_n - 1];
+                    const uint32_t lo = uni((uint32_t)(d & 0xFFFFFF)), cnt = q0 + j < lq_n ? uni((uint32_t)((d >> 24) & 0xFFFF)) : 0u;
+                    e[j] = lane < cnt ? L.cpos[lo + lane] : 0u;
+                }
+#pragma unroll 1
+                for (int j = 0; j < LDS_LB; ++j) {
+                    uint32_t e0 = e[0];
+#pragma unroll
+                    for (int x = 0; x + 1 < LDS_LB; ++x) e[x] = e[x + 1];
+                    if (q0 + j >= lq_n) break;
+                    const uint64_t d = W.lq[q0 + j];
+                    const uint32_t lo = uni((uint32_t)(d & 0xFFFFFF)), cnt = uni((uint32_t)((d >> 24) & 0xFFFF));
+                    const uint32_t meta = uni((uint32_t)(d >> 40));      // owner | ps << 6 | K << 12
+                    // ONE owner: its read's pre-filter words sit in scalar registers
+                    const uint32_t owner = meta & 63; const int kk = (int)(meta >> 12) & 63, pss = (int)(meta >> 6) & 63;
+                    const uint32_t ls = uni(W.ls[owner]);
+                    const int l = (int)(ls & 255), sd = (int)(ls >> 8);
+                    const uint64_t o0 = uni64(W.r0[owner]), o1 = uni64(W.r1[owner]);
+                    uint64_t oc0, oc1;
+                    revcomp2(o0, o1, l, oc0, oc1);
+                    const uint64_t oml0 = ones(2 * l) & M55, oml1 = ones(2 * l - 64) & M55;
+                    const uint64_t osf0 = ones(2 * sd) & M55, osf1 = ones(2 * sd - 64) & M55;
+                    const uint64_t osr0 = oml0 & ~ones(2 * (l - sd)), osr1 = oml1 & ~ones(2 * (l - sd) - 64);
+                    const uint32_t q_f = (uint32_t)o0, q_r = (uint32_t)oc0, m32 = lds_m32(l);
+                    const int off_r = l - pss - kk;
+                    for (uint32_t c = 0; c < cnt; c += 64) {
+                        if (c) e0 = c + lane < cnt ? L.cpos[lo + c + lane] : 0u;          // (a list of more than 64 entries: the further strides, one load each)
+                        if (c + lane < cnt && lds_prefilter(s_text32, L.T, e0, l, pss, off_r, q_f, q_r, m32, P.maxmm)) {
+                            const bool rev = e0 >> 31;
+                            const uint32_t w = (e0 & POS_MASK) - (uint32_t)(rev ? off_r : pss);
+                            int sm, tm;
+                            if (pos_verify_fast(P, s_text, s_bad, rev ? oc0 : o0, rev ? oc1 : o1, oml0, oml1, rev ? osr0 : osf0, rev ? osr1 : osf1, l, w, sm, tm))
+                                record(owner, sm, tm, w, rev ? 0 : 1);
+                        }
+                    }
+                }
             }
             lq_n = 0;
             wave_lds_sync();
         };
+        // the read's masks in either orientation, for the entries this lane checks itself
+        const uint64_t mr0 = R.ml[0] & ~ones(2 * (R.l - R.s)), mr1 = R.ml[1] & ~ones(2 * (R.l - R.s) - 64);
+        const uint32_t m32 = lds_m32(R.l);
         // one lookup per iteration, element 0 of the register arrays (which are shifted down each time: the loop is not
         // unrolled, so both drains are inlined once); a last iteration without a lookup empties the queues
 #pragma unroll 1
@@ -2305,15 +2512,21 @@ k_lds_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, 
             have[NL - 1] = false;
             if (!last && !__any(hv)) continue;
             // lookups that what is known by now rules out are dropped (own finds + what the drains so far brought)
-            const uint64_t known = Bst.score > W.best[0][lane] ? Bst.score : W.best[0][lane];
-            const bool need = hv && !fb && probe_needed(R, P, j, known);
+            const uint32_t known = b_sc > W.best[0][lane] ? b_sc : W.best[0][lane];
+            const bool need = hv && !fb && probe_needed(R, P, j, sc32_as_score(known));
             bool is_s = false, is_l = false;
             uint32_t cnt = 0;
             if (need) {
                 if (s0.b == CS_SINGLE) {
                     const bool rev = s0.a >> 31;
-                    int f, sm, tm; uint32_t w;
-                    if (pos_verify(P, s_text, s_bad, L.T, rev ? c0 : R.r[0], rev ? c1 : R.r[1], R.l, R.s, K, p0, s0.a, f, sm, tm, w)) pos_record(Bst, sm, tm, w, f);
+                    const int off = rev ? R.l - p0 - K : p0;
+                    if (lds_prefilter(s_text32, L.T, s0.a, R.l, off, off, (uint32_t)R.r[0], (uint32_t)c0, m32, P.maxmm)) {
+                        const uint32_t w = (s0.a & POS_MASK) - (uint32_t)off;
+                        int sm, tm;
+                        if (pos_verify_fast(P, s_text, s_bad, rev ? c0 : R.r[0], rev ? c1 : R.r[1], R.ml[0], R.ml[1], rev ? mr0 : R.ms[0], rev ? mr1 : R.ms[1], R.l, w, sm, tm))
+                            { const uint32_t x = sc32(sm, tm, w, rev ? 0 : 1), y = kx32(sm, w), z = kn32(sm, w);
+                              b_sc = x > b_sc ? x : b_sc; b_kx = y > b_kx ? y : b_kx; b_kn = z > b_kn ? z : b_kn; }
+                    }
                 } else {
                     cnt = s0.b - s0.a;
                     if (cnt > (uint32_t)LDS_MAX_LIST) fb = true;
@@ -2331,18 +2544,15 @@ k_lds_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, 
         }
         wave_lds_sync();
 
-        // ---- results
+        // ---- results: the reference of a position is a rank query on the boundary bitmap in LDS
         bool hit = false;
         if (run && !fb) {
-            const unsigned long long a = W.best[0][lane], b2 = W.best[1][lane], c2 = W.best[2][lane];
-            Bst.score = a > Bst.score ? a : Bst.score; Bst.kmax = b2 > Bst.kmax ? b2 : Bst.kmax; Bst.kmin = c2 > Bst.kmin ? c2 : Bst.kmin;
-            if (Bst.score) {
+            const uint32_t a = W.best[0][lane], b2 = W.best[1][lane], c2 = W.best[2][lane];
+            b_sc = a > b_sc ? a : b_sc; b_kx = b2 > b_kx ? b2 : b_kx; b_kn = c2 > b_kn ? c2 : b_kn;
+            if (b_sc) {
                 hit = true;
-                const uint32_t r = ref_of(L, (uint32_t)(Bst.score >> 1));
-                const uint32_t pmax = (uint32_t)Bst.kmax, pmin = 0xFFFFFFFFu - (uint32_t)Bst.kmin;
-                const uint32_t r0 = L.ref_start[r], r1 = L.ref_start[r + 1];
-                bool amb = false;
-                if (pmin < r0 || pmax >= r1) amb = ref_of(L, pmax) != ref_of(L, pmin);
+                const uint32_t r = ref_at((b_sc >> 1) & 0xFFFFFFu);
+                const bool amb = ref_at(b_kx & 0xFFFFFFu) != ref_at(0xFFFFFFu - (b_kn & 0xFFFFFFu));
                 ann_round[u] = (uint8_t)(RN + 1); ann_ref[u] = (int32_t)r; ann_amb[u] = (uint8_t)amb;
             }
         }
@@ -2352,18 +2562,20 @@ k_lds_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, 
         if (sv) {
             uint32_t base = 0;
             if (lane == 0) base = (uint32_t)atomicAdd(next_n, (unsigned long long)__popcll(sv));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            base = uni(base);
             const uint32_t at = base + (uint32_t)__popcll(sv & below);
             if (surv && at < next_cap) next_list[at] = u;       // (cannot fail: cap = the tiles that share the sub-list x 64)
         }
         if (fv) {
             uint32_t base = 0;
             if (lane == 0) base = (uint32_t)atomicAdd(fb_n, (unsigned long long)__popcll(fv));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            base = uni(base);
             if (fb) fb_list[base + (uint32_t)__popcll(fv & below)] = u;
         }
         wave_lds_sync();                                           // the wave's LDS area is rewritten by its next tile
+        t = tn; u = un; k[0] = kn[0]; k[1] = kn[1]; done_before = done_n; from_list = nlist;
     }
+    (void)from_list;
     if (lane == 0) {
         const uint32_t slot_ = gw & (STAT_SLOTS - 1);
         if (n_act) atomicAdd(&stats[(size_t)slot_ * 8], (unsigned long long)n_act);

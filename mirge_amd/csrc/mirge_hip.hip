@@ -100,7 +100,8 @@ struct Lib {
     DevBuf slots, sbits, pent, ppre; uint64_t n_slots = 0, n_bitw = 0, n_pent = 0; bool has_both = false;
     // compact form of the same tables (kernels.h: LibDev::cslots) for a library whose text fits the LDS: 8-byte slots,
     // 4-byte entries; n_slots / n_bitw / n_pent, ctab and sch then count and describe these
-    DevBuf cslots, cpos; bool has_compact = false; uint32_t lds_tw = 0, lds_bw = 0;
+    DevBuf cslots, cpos, sep, rank; bool has_compact = false; uint32_t lds_tw = 0, lds_bw = 0, lds_sw = 0;
+    std::vector<uint64_t> h_sep; bool has_n = false;         // host: the separators' bitmap (until the compact tables are built), any reference N?
     TabDesc ctab{0, 0, 0}; std::vector<TabDesc> sch;
     LibDev dev() const {
         LibDev L;
@@ -112,10 +113,11 @@ struct Lib {
         L.nsch = (int)sch.size();
         for (int j = 0; j < MAX_SCHEMES; ++j) L.sch[j] = j < L.nsch ? sch[j] : TabDesc{0, 0, 0};
         L.cslots = has_compact ? cslots.as<CSlot>() : nullptr; L.cpos = cpos.as<uint32_t>();
-        L.lds_tw = has_compact ? lds_tw : 0; L.lds_bw = has_compact ? lds_bw : 0;
+        L.lds_tw = has_compact ? lds_tw : 0; L.lds_bw = has_compact ? lds_bw : 0; L.lds_sw = has_compact ? lds_sw : 0;
+        L.sep = lds_sw ? sep.as<uint64_t>() : nullptr; L.rank = rank.as<uint32_t>();
         return L;
     }
-    void release() { cslots.release(); cpos.release(); has_compact = false; text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); slots.release(); sbits.release(); pent.release(); ppre.release(); sch.clear(); n_slots = n_bitw = n_pent = 0; has_both = false; loaded = false; }
+    void release() { cslots.release(); cpos.release(); sep.release(); rank.release(); has_compact = false; text.release(); bad.release(); koff.release(); kent.release(); kpre.release(); kbits.release(); dref.release(); dlut.release(); slots.release(); sbits.release(); pent.release(); ppre.release(); sch.clear(); n_slots = n_bitw = n_pent = 0; has_both = false; loaded = false; }
 };
 
 constexpr size_t STAT_WORDS = 2 * STAT_SLOTS * 8;         // uint64 words of counters per round
@@ -227,7 +229,7 @@ struct mirge_ctx {
     std::vector<uint64_t> csr_off; std::vector<uint32_t> csr_sample, csr_count;
     std::string uniq_seq; std::vector<uint32_t> uniq_counts;
     // timing
-    std::vector<KTime> kt;
+    std::vector<KTime> kt; bool timing = true;          // mirge_set_kernel_timing
     double collapse_ms = 0, annotate_ms = 0, counts_ms = 0;
 };
 
@@ -250,8 +252,9 @@ KTime& ktime(mirge_ctx* c, const char* name) {
     return c->kt.back();
 }
 // a timing mark that could not be recorded leaves the entry unused (no time is reported for it) instead of a stale one
-void kt_begin(mirge_ctx* c, const char* name, hipStream_t st = nullptr) { KTime& k = ktime(c, name); k.ok = k.a && k.b && hipEventRecord(k.a, st ? st : c->st) == hipSuccess; }
+void kt_begin(mirge_ctx* c, const char* name, hipStream_t st = nullptr) { if (!c->timing) return; KTime& k = ktime(c, name); k.ok = k.a && k.b && hipEventRecord(k.a, st ? st : c->st) == hipSuccess; }
 void kt_end(mirge_ctx* c, const char* name, uint64_t bytes, hipStream_t st = nullptr) {
+    if (!c->timing) return;
     KTime& k = ktime(c, name);
     k.ok = k.ok && hipEventRecord(k.b, st ? st : c->st) == hipSuccess;
     k.used = k.ok; k.bytes = bytes; k.ms = -1;
@@ -299,7 +302,7 @@ bool bits_wanted(uint64_t nbk) {                 // an occupancy bitmap in front
 // One table: 2T entries (every position under its own key and under the reverse strand's) appended to `pent`, nbk = 4^k
 // slots and nbk / 32 occupancy words appended to the library's slot / occupancy buffers (all grown here).
 // B = 0: the contiguous k-mer table; else the table of one shape (block mask) of a block scheme.
-int build_both(mirge_ctx* c, Lib& L, int k, int B, uint32_t mask, bool compact = false) {
+int build_both(mirge_ctx* c, Lib& L, int k, uint32_t B, uint32_t mask, bool compact = false) {
     const uint64_t nbk = 1ull << (2 * k), T = L.T, base = L.n_pent;
     if (base + 2 * T >= 0xFFFFFFF0ull || L.n_slots + nbk >= 0xFFFFFFF0ull || L.n_bitw + nbk / 32 >= (1ull << 27))
         return fail(c, MIRGE_E_LIMIT, "seed tables of a library exceed 2^32 entries");
@@ -344,48 +347,71 @@ int build_contig_both(mirge_ctx* c, Lib& L) {
     L.has_both = true;
     return MIRGE_OK;
 }
-// A library whose text + N bitmap a block can stage into LDS next to its waves' queues takes the compact tables and
-// k_lds_round.  MIRGE_LDS = 0: never (A/B aid); MIRGE_LDS_MAX = bytes of text + bitmap (default 40 KB: two blocks per CU).
+// A library whose text + N bitmap a block can stage into LDS next to its waves' queues CAN take the compact tables and
+// k_lds_round: MIRGE_LDS = 1.  Off by default -- measured on MI355X (profiles/r03/lds_path.txt) the path loses to the
+// probe kernel in time (round 5: 0.57 against 0.40 ms, round 1: 0.15 against 0.13) and moves the same bytes past the L2
+// (2.3 GB in round 5 either way: what the L2 misses are the random 128-B lines of slots and lists, whose count does
+// not depend on the entry size).  MIRGE_LDS_MAX = bytes of text + bitmap (default 40 KB: two blocks per CU).
 uint64_t lds_lib_max() { if (const char* e = getenv("MIRGE_LDS_MAX")) return strtoull(e, nullptr, 10); return 40u << 10; }
 bool lds_wanted(const Lib& L) {
-    if (const char* e = getenv("MIRGE_LDS")) { if (atoi(e) == 0) return false; }
+    { const char* e = getenv("MIRGE_LDS"); if (!e || atoi(e) == 0) return false; }
     if (L.T == 0) return false;
     const uint64_t tw = L.T / 32 + 3, bw = L.T / 64 + 2;
-    // entries of every table the library can get: the contiguous one + schemes (4,1), (5,2), (4,2), (3,2) = 1 + 4 + 18
-    return (tw + bw) * 8 <= lds_lib_max() && 2 * L.T * 23 < LDS_MAX_ENTRIES;
+    // text + bitmap(s) + rank words; entries of every table the library can get: the contiguous one + schemes (4,1), (5,2), (4,2), (3,2) = 1 + 4 + 18
+    return (tw + bw * (L.has_n ? 2 : 1)) * 8 + bw * 4 <= lds_lib_max() && 2 * L.T * 23 < LDS_MAX_ENTRIES && L.T < (1u << 24);
 }
+size_t lds_lib_bytes(const LibDev& L) { return ((size_t)L.lds_tw + L.lds_bw + L.lds_sw + (L.lds_bw + 1) / 2) * 8; }
 int build_contig_compact(mirge_ctx* c, Lib& L) {
     const uint64_t nbk = 1ull << (2 * L.kb);
     // an occupancy bitmap in front of the slots pays where most buckets are empty (it is 1/64 of the slots' bytes)
     L.ctab = TabDesc{(uint32_t)L.n_slots, (uint32_t)L.n_bitw, tab_info(L.kb, 0, 0, nbk >= 8 * L.T)};
     int rc = build_both(c, L, L.kb, 0, 0u, true);
     if (rc) return rc;
-    L.has_compact = true; L.lds_tw = (uint32_t)(L.T / 32 + 3); L.lds_bw = (uint32_t)(L.T / 64 + 2);
+    L.lds_tw = (uint32_t)(L.T / 32 + 3); L.lds_bw = (uint32_t)(L.T / 64 + 2); L.lds_sw = L.has_n ? L.lds_bw : 0;
+    // the reference of a position = the separators before it: per bitmap word a running count, the rest is a popcount
+    std::vector<uint32_t> rank(L.lds_bw, 0);
+    uint32_t run = 0;
+    for (uint32_t j = 0; j < L.lds_bw; ++j) { rank[j] = run; run += (uint32_t)__builtin_popcountll(j < L.h_sep.size() ? L.h_sep[j] : 0ull); }
+    HIPCHK(c, L.rank.ensure((size_t)L.lds_bw * 4, false, 0, c->st));
+    HIPCHK(c, hipMemcpyAsync(L.rank.p, rank.data(), (size_t)L.lds_bw * 4, hipMemcpyHostToDevice, c->st));
+    if (L.has_n) {
+        HIPCHK(c, L.sep.ensure((size_t)L.lds_bw * 8, false, 0, c->st));
+        HIPCHK(c, hipMemcpyAsync(L.sep.p, L.h_sep.data(), (size_t)L.lds_bw * 8, hipMemcpyHostToDevice, c->st));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));                    // rank is a vector of this frame
+    L.has_compact = true;
     return MIRGE_OK;
 }
-// Block scheme (B, m) of a library (kernels.h: block schemes), built the first time a cascade holds a round that can use it.
-int ensure_scheme(mirge_ctx* c, Lib& L, int B, int m) {
+// Block scheme (blocks, m) of a library (kernels.h: block schemes), built the first time a cascade holds a round that can use it.
+int ensure_scheme(mirge_ctx* c, Lib& L, uint32_t blocks, int m) {
     if (!L.loaded || !(L.has_both || L.has_compact) || L.T == 0) return MIRGE_OK;
-    for (auto& x : L.sch) if (tab_B(x) == B && tab_m(x) == m) return MIRGE_OK;
+    for (auto& x : L.sch) if (tab_blocks(x) == blocks && tab_m(x) == m) return MIRGE_OK;
     if ((int)L.sch.size() >= MAX_SCHEMES) return MIRGE_OK;
-    const int ns = scheme_nshapes(m), kbs = std::min((4 - m) * B, L.kb);
+    const int ns = scheme_nshapes(m), kbs = std::min(scheme_max_sel(blocks, m), L.kb);
     const uint64_t nbk = 1ull << (2 * kbs);
     if (L.n_pent + (uint64_t)ns * 2 * L.T >= 0xFFFFFFF0ull || L.n_slots + ns * nbk >= 0xFFFFFFF0ull) return MIRGE_OK;    // too large a library: its short reads stay with the generic kernel
     if (L.has_compact && L.n_pent + (uint64_t)ns * 2 * L.T >= LDS_MAX_ENTRIES) return MIRGE_OK;
-    const TabDesc t{(uint32_t)L.n_slots, (uint32_t)L.n_bitw, tab_info(kbs, B, m, L.has_compact ? nbk >= 8 * L.T : bits_wanted(nbk))};
-    for (int i = 0; i < ns; ++i) { int rc = build_both(c, L, kbs, B, scheme_shape(m, i), L.has_compact); if (rc) return rc; }
+    const TabDesc t{(uint32_t)L.n_slots, (uint32_t)L.n_bitw, tab_info(kbs, blocks, m, L.has_compact ? nbk >= 8 * L.T : bits_wanted(nbk))};
+    for (int i = 0; i < ns; ++i) { int rc = build_both(c, L, kbs, blocks, scheme_shape(m, i), L.has_compact); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->st));
     L.sch.push_back(t);
     return MIRGE_OK;
 }
-// the schemes a round can use: B = 4 for one mismatch (12-nt shapes), B = 3, 4, 5 for two (6 / 8 / 10-nt shapes)
+// the schemes a round can use: (4,4,4,4) for one mismatch (12-nt shapes); for two (5,5,5,5), (4,4,4,4), (3,3,3,3) (10 / 8 /
+// 6-nt shapes) and, between the last two, windows of exactly 15 / 14 / 13 nt -- (4,4,4,3), (4,4,3,3), (4,3,3,3): 7-8 / 6-8 /
+// 6-7-nt shapes -- for the reads that short (MIRGE_SCHEMES_UNEQ = 0: without these, A/B aid)
 int ensure_schemes(mirge_ctx* c, Lib& L, const mirge_round& R) {
     if (const char* env = getenv("MIRGE_SCHEMES")) { if (atoi(env) == 0) return MIRGE_OK; }      // A/B aid
+    bool uneq = true;
+    if (const char* env = getenv("MIRGE_SCHEMES_UNEQ")) uneq = atoi(env) != 0;
     const int ms = std::min(R.seedmm, R.maxmm);
     int rc = MIRGE_OK;
     auto want = [&](int m) {
-        if (m == 1 && !rc) rc = ensure_scheme(c, L, 4, 1);
-        if (m == 2) for (int B = 5; B >= 3 && !rc; --B) rc = ensure_scheme(c, L, B, 2);
+        if (m == 1 && !rc) rc = ensure_scheme(c, L, blocks_eq(4), 1);
+        if (m == 2) {
+            static const uint32_t bl[6] = {0x5555u, 0x4444u, 0x3444u, 0x3344u, 0x3334u, 0x3333u};
+            for (int j = 0; j < 6 && !rc; ++j) if (uneq || bl[j] == blocks_eq(blk(bl[j], 0))) rc = ensure_scheme(c, L, bl[j], 2);
+        }
     };
     want(ms);
     if (R.maxmm != ms && R.seedlen < 20) want(R.maxmm);         // windows that reach beyond a short seed fall under the whole-read allowance
@@ -402,6 +428,7 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
     if (T >= (1ull << 31)) return fail(c, MIRGE_E_LIMIT, "library larger than 2^31 nt");
     size_t words = (size_t)(T / 32) + 10, bwords = (size_t)(T / 64) + 10;
     std::vector<uint64_t> text(words, 0), bad(bwords, 0);
+    L.h_sep.assign(bwords, 0); L.has_n = false;
     L.ref_start.assign(n + 1, 0);
     uint64_t p = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -411,9 +438,10 @@ int load_library(mirge_ctx* c, int lib, std::vector<std::string>&& names, const 
             if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32);
             int code = base_code(ch);
             if (code >= 0 && code < 4) text[p >> 5] |= (uint64_t)code << (2 * (p & 31));
-            else bad[p >> 6] |= 1ull << (p & 63);                 // reference N: not alignable
+            else { bad[p >> 6] |= 1ull << (p & 63); L.has_n = true; }      // reference N: not alignable
         }
         bad[p >> 6] |= 1ull << (p & 63);                           // separator
+        L.h_sep[p >> 6] |= 1ull << (p & 63);
         ++p;
     }
     L.ref_start[n] = (uint32_t)p;
@@ -715,7 +743,7 @@ int collapse_settle(mirge_ctx* c, bool& reran) {
     int rc = collapse_finish<2>(c, c->cls[0], "collapse_emit16");
     int r1 = collapse_finish<6>(c, c->cls[1], "collapse_emit48");
     if (!rc) rc = r1;
-    float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_c[0], c->ev_c[1]); c->collapse_ms = ms;
+    float ms = 0; if (c->timing) (void)hipEventElapsedTime(&ms, c->ev_c[0], c->ev_c[1]); c->collapse_ms = ms;
     return rc;
 }
 
@@ -724,13 +752,13 @@ int collapse_packed(mirge_ctx* c, const void* d16, uint64_t n16, const void* d48
     c->annotated = false; c->counts_valid = false; c->host_valid = false;
     kt_clear(c, "collapse");
     hipEvent_t a = c->ev_c[0], b = c->ev_c[1];
-    HIPCHK(c, hipEventRecord(a, c->st));
+    if (c->timing) HIPCHK(c, hipEventRecord(a, c->st));
     int rc = collapse_both(c, (const uint64_t*)d16, n16, nullptr, (const uint64_t*)d48, n48, nullptr, sample, defer);
     if (!rc) {
-        HIPCHK(c, hipEventRecord(b, c->st));
+        if (c->timing) HIPCHK(c, hipEventRecord(b, c->st));
         if (defer) return MIRGE_OK;
         HIPCHK(c, hipStreamSynchronize(c->st));
-        float ms = 0; (void)hipEventElapsedTime(&ms, a, b); c->collapse_ms = ms;
+        float ms = 0; if (c->timing) (void)hipEventElapsedTime(&ms, a, b); c->collapse_ms = ms;
         kt_resolve(c);
     }
     return rc;
@@ -1231,8 +1259,9 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
         // the LDS path (kernels.h: k_lds_round): persistent blocks with the library's text in LDS, then the generic
         // kernel over the reads it handed on
         const RoundSch RS = round_schemes(L, P);
-        auto kern = RS.n == 0 ? k_lds_round<RN, 0> : (RS.n == 1 ? k_lds_round<RN, 1> : k_lds_round<RN, ROUND_SCHEMES>);
-        const size_t lds = ((size_t)L.lds_tw + L.lds_bw) * 8 + (size_t)LDS_WAVES * sizeof(LdsWave);
+        auto kern = RS.n == 0 ? k_lds_round<RN, 0> : ((RS.n == 1 && blocks_equal(tab_blocks(RS.t[0]))) ? k_lds_round<RN, 1> : k_lds_round<RN, ROUND_SCHEMES>);      // (<.., 1>: one scheme, of equal blocks)
+        const int LDS_BLOCK = RS.n == 0 ? LdsCfg<0>::BLOCK : LdsCfg<1>::BLOCK, LDS_WAVES = LDS_BLOCK / 64;
+        const size_t lds = lds_lib_bytes(L) + (size_t)LDS_WAVES * sizeof(LdsWave);
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const uint64_t tiles = in.K > 1 ? (uint64_t)in.K * (in.cap / 64) : (UB + 63) / 64;
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160u << 10) / (lds + 512)));
@@ -1256,7 +1285,7 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
         // the probe path (kernels.h: k_probe_round) for what the slot tables can serve, then the generic kernel over the
         // reads it handed on
         const RoundSch RS = round_schemes(L, P);
-        auto kern = RS.n == 0 ? k_probe_round<RN, 0> : (RS.n == 1 ? k_probe_round<RN, 1> : k_probe_round<RN, ROUND_SCHEMES>);
+        auto kern = RS.n == 0 ? k_probe_round<RN, 0> : ((RS.n == 1 && blocks_equal(tab_blocks(RS.t[0]))) ? k_probe_round<RN, 1> : k_probe_round<RN, ROUND_SCHEMES>);      // (<.., 1>: one scheme, of equal blocks)
         const uint32_t grid = in.K > 1 ? in.K * (in.cap / PB) : (uint32_t)((UB + PB - 1) / PB);
         const uint32_t cap_out = (grid + LIST_K - 1) / LIST_K * PB;          // blocks that share a sub-list x what each can append
         ListOut out{nullptr, nullptr, 0, 0};
@@ -1277,7 +1306,7 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
     // the generic kernel as the round's matcher: it reads whatever layout the previous round left (and the leftovers'
     // list), and writes one dense list
     if (writes) { C.lf[r + 1].K = 1; C.lf[r + 1].cap = 0; }
-    hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((UB + MB - 1) / MB)), dim3(MB), 0, C.st,
+    hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)((UB + MatchTile<KW>::N - 1) / MatchTile<KW>::N)), dim3(MB), 0, C.st,
                        C.ukeys.as<uint64_t>(), (uint32_t)UB, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
                        C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
                        in, fbs_in, (const unsigned long long*)(C.fbs_n + r),
@@ -1380,6 +1409,8 @@ int annotate_verb(mirge_ctx* c) {
     return MIRGE_OK;
 }
 
+static const char* kRoundNames48[MIRGE_MAX_ROUNDS] = {"match_round1_48", "match_round2_48", "match_round3_48", "match_round4_48",
+                                                      "match_round5_48", "match_round6_48", "match_round7_48", "match_round8_48"};
 static const char* kRoundNames[MIRGE_MAX_ROUNDS] = {"match_round1", "match_round2", "match_round3", "match_round4",
                                                     "match_round5", "match_round6", "match_round7", "match_round8"};
 
@@ -1432,7 +1463,7 @@ int annotate(mirge_ctx* c) {
     c->cls[0].fbs_n = c->cls[0].fb_n + MIRGE_MAX_ROUNDS; c->cls[1].fbs_n = c->cls[0].fbs_n;       // (the 48-byte class has no such lists: its launches get none)
     HIPCHK(c, hipMemsetAsync(c->state.p, 0, w_all * 8, c->st));
     hipEvent_t e0 = c->ev_t[0], e1 = c->ev_t[1], e2 = c->ev_t[2];
-    HIPCHK(c, hipEventRecord(e0, c->st));
+    if (c->timing) HIPCHK(c, hipEventRecord(e0, c->st));
     // the 48-byte class (reads with N or longer than 56 nt: a fraction of a percent) runs its cascade on st2 beside
     // the 16-byte class; the two meet only in atomically updated counters.  Kernel times are those of the 16-byte class.
     { int rc = fork_st2(c); if (rc) return rc; }
@@ -1440,18 +1471,27 @@ int annotate(mirge_ctx* c) {
         kt_begin(c, kRoundNames[r]);
         int rc = annotate_class<2>(c, c->cls[0], r, c->rounds[r]);
         kt_end(c, kRoundNames[r], 0);
+        // the 48-byte class's launches are timed by name as well (on their own stream): they overlap the 16-byte class's,
+        // so their times are not summands of the step -- but whichever chain is longer is what the join waits for
+        const bool t48 = table_bound(c->cls[1]) > 0;
+        if (t48) kt_begin(c, kRoundNames48[r], c->st2);
         if (!rc) rc = annotate_class<6>(c, c->cls[1], r, c->rounds[r]);
+        if (t48) kt_end(c, kRoundNames48[r], (uint64_t)52 * table_bound(c->cls[1]), c->st2);      // (bytes: an upper bound -- the round statistics do not tell the classes apart)
         if (rc) return rc;
     }
-    HIPCHK(c, hipEventRecord(e1, c->st));
+    if (c->timing) HIPCHK(c, hipEventRecord(e1, c->st));
     kt_begin(c, "counts");
     int rc = counts_class<2>(c, c->cls[0], M);
     kt_end(c, "counts", (c->cls[0].coo_n + c->cls[1].coo_n) * 8 + (uint64_t)16 * M * S);
-    if (!rc) rc = counts_class<6>(c, c->cls[1], M);
+    if (!rc && table_bound(c->cls[1]) > 0) {
+        kt_begin(c, "counts_48", c->st2);
+        rc = counts_class<6>(c, c->cls[1], M);
+        kt_end(c, "counts_48", (c->cls[1].coo_n + c->cls[1].pend_n) * 8, c->st2);
+    }
     if (!rc) rc = annotate_verb(c);
     if (rc) return rc;
     { int rj = join_st2(c); if (rj) return rj; }
-    HIPCHK(c, hipEventRecord(e2, c->st));
+    if (c->timing) HIPCHK(c, hipEventRecord(e2, c->st));
     HIPCHK(c, hipMemcpyAsync(c->h_state, c->state.p, w_out * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     if (c->cls[0].pending || c->cls[1].pending) {
@@ -1467,8 +1507,8 @@ int annotate(mirge_ctx* c) {
     c->h_len.assign(hraw + w_stats + 2 * qn + w_cat, hraw + w_stats + 2 * qn + w_cat + w_len);
     c->h_tu.assign(hraw + w_out - w_tu, hraw + w_out);
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1); c->annotate_ms = ms;
-    (void)hipEventElapsedTime(&ms, e1, e2); c->counts_ms = ms;
+    c->annotate_ms = 0; c->counts_ms = 0;
+    if (c->timing) { (void)hipEventElapsedTime(&ms, e0, e1); c->annotate_ms = ms; (void)hipEventElapsedTime(&ms, e1, e2); c->counts_ms = ms; }
     kt_resolve(c);
     uint64_t hs[MIRGE_MAX_ROUNDS * 2] = {};
     for (int r = 0; r < c->n_rounds; ++r)
@@ -1484,9 +1524,9 @@ int annotate(mirge_ctx* c) {
 #endif
     for (int r = 0; r < c->n_rounds; ++r) {
         c->stats[r][0] = hs[2 * r]; c->stats[r][1] = hs[2 * r + 1];
-        c->round_ms[r] = ktime(c, kRoundNames[r]).ms;
+        c->round_ms[r] = c->timing ? ktime(c, kRoundNames[r]).ms : 0.0;
         // algorithmic bytes of the round: 20 B per eligible unique + the 2-bit library once
-        ktime(c, kRoundNames[r]).bytes = 20 * hs[2 * r] + c->libs[c->rounds[r].lib].T / 4;
+        if (c->timing) ktime(c, kRoundNames[r]).bytes = 20 * hs[2 * r] + c->libs[c->rounds[r].lib].T / 4;
     }
     c->annotated = true; c->counts_valid = true; c->host_valid = false;
     return MIRGE_OK;
@@ -2226,6 +2266,13 @@ int32_t mirge_last_timing(const mirge_ctx* c, double* collapse_ms, double* annot
     if (collapse_ms) *collapse_ms = c->collapse_ms;
     if (annotate_ms) *annotate_ms = c->annotate_ms;
     if (counts_ms) *counts_ms = c->counts_ms;
+    return MIRGE_OK;
+}
+
+int32_t mirge_set_kernel_timing(mirge_ctx* c, int32_t on) {
+    if (!c) return MIRGE_E_ARG;
+    c->timing = on != 0;
+    if (!c->timing) for (auto& k : c->kt) { k.used = false; k.ms = 0; }
     return MIRGE_OK;
 }
 

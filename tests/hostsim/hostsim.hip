@@ -22,7 +22,7 @@ struct SimLib {
                          L.slots = slots.empty() ? nullptr : slots.data(); L.sbits = sbits.data(); L.pent = pent.data(); L.ppre = nullptr; L.ctab = ctab;
                          L.nsch = (int)sch.size();
                          for (int j = 0; j < MAX_SCHEMES; ++j) L.sch[j] = j < L.nsch ? sch[j] : TabDesc{0, 0, 0};
-                         L.cslots = cslots.empty() ? nullptr : cslots.data(); L.cpos = cpos.data(); L.lds_tw = T / 32 + 3; L.lds_bw = T / 64 + 2;
+                         L.cslots = cslots.empty() ? nullptr : cslots.data(); L.cpos = cpos.data(); L.lds_tw = T / 32 + 3; L.lds_bw = T / 64 + 2; L.lds_sw = 0; L.sep = nullptr; L.rank = nullptr;
                          return L; }
 };
 
@@ -62,7 +62,7 @@ void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb,
     if ((flags & 1) && T > 0) {
         const bool ubits = !(flags & 2), compact = flags & 4;
         const LibDev LD = S->dev();                                      // text, N bitmap and reference offsets are in place
-        auto build_c = [&](int k, int B, uint32_t mask) {                // as build_both(..., compact) in mirge_hip.hip
+        auto build_c = [&](int k, uint32_t B, uint32_t mask) {                // as build_both(..., compact) in mirge_hip.hip
             const uint64_t nbk = 1ull << (2 * k), base = S->cpos.size(), s0 = S->cslots.size(), w0 = S->sbits.size();
             S->cpos.resize(base + 2 * (size_t)T); S->cslots.resize(s0 + nbk); S->sbits.resize(w0 + nbk / 32, 0);
             std::vector<uint32_t> off(nbk + 1, 0);
@@ -80,9 +80,9 @@ void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb,
                 S->cslots[s0 + b] = e;
             }
         };
-        auto build_p = [&](int k, int B, uint32_t mask) {
+        auto build_p = [&](int k, uint32_t B, uint32_t mask) {
             const uint64_t nbk = 1ull << (2 * k), base = S->pent.size(), s0 = S->slots.size(), w0 = S->sbits.size();
-            const int K = B ? 4 * B : k;
+            const int K = B ? blocks_W(B) : k;
             S->pent.resize(base + 2 * (size_t)T);
             S->slots.resize(s0 + nbk); S->sbits.resize(w0 + nbk / 32, 0);
             std::vector<uint32_t> off(nbk + 1, 0);
@@ -103,12 +103,12 @@ void* sim_lib_new(int32_t n, const char* seqs, const uint64_t* offs, int32_t kb,
                 S->slots[s0 + b] = e;
             }
         };
-        auto build = [&](int k, int B, uint32_t mask) { if (compact) build_c(k, B, mask); else build_p(k, B, mask); };
+        auto build = [&](int k, uint32_t B, uint32_t mask) { if (compact) build_c(k, B, mask); else build_p(k, B, mask); };
         S->ctab = TabDesc{0, 0, tab_info(kb, 0, 0, ubits)};
         build(kb, 0, 0u);
-        const int BM[4][2] = {{4, 1}, {5, 2}, {4, 2}, {3, 2}};
-        for (int j = 0; j < 4; ++j) {
-            const int B = BM[j][0], m = BM[j][1], kbs = std::min((4 - m) * B, kb);
+        const uint32_t BM[7][2] = {{0x4444u, 1}, {0x5555u, 2}, {0x4444u, 2}, {0x3444u, 2}, {0x3344u, 2}, {0x3334u, 2}, {0x3333u, 2}};
+        for (int j = 0; j < 7; ++j) {
+            const uint32_t B = BM[j][0]; const int m = (int)BM[j][1], kbs = std::min(scheme_max_sel(B, m), kb);
             S->sch.push_back(TabDesc{(uint32_t)(compact ? S->cslots.size() : S->slots.size()), (uint32_t)S->sbits.size(), tab_info(kbs, B, m, ubits)});
             for (int i = 0; i < scheme_nshapes(m); ++i) build(kbs, B, scheme_shape(m, i));
         }

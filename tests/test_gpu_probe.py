@@ -13,8 +13,11 @@ from tests.test_gpu_parity import _compare_with_oracle
 pytestmark = pytest.mark.gpu
 
 
+# lds = "1": libraries whose text fits the LDS take the compact tables and k_lds_round (off by default), the others the probe kernel
+@pytest.mark.parametrize("lds", ["0", "1"])
 @pytest.mark.parametrize("kb,bits", [(6, "4194304"), (9, "4194304"), (10, "0"), (12, "4194304"), (12, "0")])
-def test_default_cascade_through_slot_tables(oracle, monkeypatch, kb, bits):
+def test_default_cascade_through_slot_tables(oracle, monkeypatch, kb, bits, lds):
+    monkeypatch.setenv("MIRGE_LDS", lds)
     monkeypatch.setenv("MIRGE_SLOTS_MIN_KB", "4")
     monkeypatch.setenv("MIRGE_KB", str(kb))
     monkeypatch.setenv("MIRGE_BITS2_MAX", bits)           # 0: slots read without asking the occupancy bits
@@ -29,10 +32,12 @@ def test_default_cascade_through_slot_tables(oracle, monkeypatch, kb, bits):
         assert (res["ann_round"] == r).sum() > 0, r
 
 
+@pytest.mark.parametrize("lds", ["0", "1"])
 @pytest.mark.parametrize("seed,kb", [(11, 7), (12, 10), (13, 12), (14, 11)])
-def test_random_cascades_through_slot_tables(oracle, monkeypatch, seed, kb):
+def test_random_cascades_through_slot_tables(oracle, monkeypatch, seed, kb, lds):
     """As test_gpu_parity.py::test_random_cascades_vs_oracle, with every library carrying slot tables: rounds of one or
     two pieces run on the probe path, the others (and the 48-byte key class) on the generic kernel."""
+    monkeypatch.setenv("MIRGE_LDS", lds)
     monkeypatch.setenv("MIRGE_SLOTS_MIN_KB", "4")
     monkeypatch.setenv("MIRGE_KB", str(kb))
     rng = np.random.default_rng(2000 + seed)
@@ -62,8 +67,9 @@ def test_random_cascades_through_slot_tables(oracle, monkeypatch, seed, kb):
     assert sum(b for _, b in stats) > 1000
 
 
+@pytest.mark.parametrize("lds", ["0", "1"])
 @pytest.mark.parametrize("seed", [21, 22, 23])
-def test_cascades_that_mix_probe_and_generic_rounds(oracle, monkeypatch, seed):
+def test_cascades_that_mix_probe_and_generic_rounds(oracle, monkeypatch, seed, lds):
     """Libraries with and without slot tables in one cascade: a probe round leaves split survivor lists (kernels.h:
     ListOut) and a list of the generic kernel's leftovers, a round whose library has no slot tables reads both with the
     generic kernel and leaves one dense list, which the next probe round reads -- every hand-over between the two list
@@ -74,6 +80,7 @@ def test_cascades_that_mix_probe_and_generic_rounds(oracle, monkeypatch, seed):
     cut = sorted(kbs.values())[2]                            # the two largest libraries get slot tables, the others none
     assert min(kbs.values()) < cut <= max(kbs.values()), kbs
     monkeypatch.setenv("MIRGE_SLOTS_MIN_KB", str(cut))
+    monkeypatch.setenv("MIRGE_LDS", lds)
     rng = np.random.default_rng(3000 + seed)
     samples = [synth.make_reads(libs, 30000, 810 + seed)]
     seqs, lens = samples[0]

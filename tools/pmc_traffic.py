@@ -22,9 +22,9 @@ def key_of(name):
     m = re.search(r"k_match_round<(\d+), (\d+)>", name)
     if m:
         return "match_round%d%s" % (int(m.group(2)) + 1, "" if m.group(1) == "2" else "_48")
-    m = re.search(r"k_probe_round<(\d+), (\d+)>", name)
+    m = re.search(r"k_(probe|lds)_round<(\d+), (\d+)>", name)
     if m:
-        return "match_round%d" % (int(m.group(1)) + 1)
+        return "match_round%d" % (int(m.group(2)) + 1)
     if "k_part_pass" in name:
         return "collapse_part16"
     if "k_part_fold" in name:
@@ -58,7 +58,10 @@ def main(a):
     f = load(fetch_csv, "FETCH_SIZE", steps, warmup)
     w = load(write_csv, "WRITE_SIZE", steps, warmup)
     ks = sorted(set(f) | set(w))
-    json.dump({"unit": "bytes per launch", "reads": reads, "profile": profile,
+    import hashlib, os
+    so = os.environ.get("MIRGE_HIP_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mirge_amd", "libmirge_hip.so")
+    sha = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16] if os.path.exists(so) else None
+    json.dump({"unit": "bytes per launch", "reads": reads, "profile": profile, "lib_sha16": sha,
                "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB * 1024), mean of the last "
                        "%d steps of each kernel; kernels = 2*FETCH + WRITE per MI355X_MICROARCH.md (gfx950 FETCH_SIZE "
                        "counts 64 B per 128-B request); uncalibrated for scattered 16-B accesses; Infinity-Cache hits "
