@@ -1256,6 +1256,7 @@ struct ProbeRead {
     int ps[3];                // plain pieces: where their k-mers start in the read
     bool lead;                // scheme: shape 0 lies inside the seed, so it finds every stratum-0 alignment
     bool ok, served;          // ok: bowtie aligns the read at all; served: the probe path can decide it
+    uint64_t nraw;            // 48-byte class: the read's N, one bit per nt (a read N mismatches everything; 0 for 16-byte keys)
 };
 MG_HD void probe_masks(ProbeRead& R) {
     R.ml[0] = ones(2 * R.l) & M55; R.ml[1] = ones(2 * R.l - 64) & M55;
@@ -1274,16 +1275,21 @@ MG_HD int pre_mism(uint64_t rr, uint64_t mask, uint64_t pre) {
     return popc64((d | (d >> 1)) & mask);
 }
 // NS = schemes of RS looked at (a template parameter of the kernel: rounds without schemes carry none of it)
-template <int NS>
+// KW = 6: a read of the 48-byte class -- served if it is at most 56 nt after -5 / -3 (two words, as a 16-byte key's);
+// its N count as mismatches in probe_verify, and a lookup whose key holds one is left out (probe_lookup_n)
+template <int NS, int KW = 2>
 MG_HD void probe_setup(const uint64_t* key, const LibDev& L, const RoundDev& P, const RoundSch& RS, ProbeRead& R) {
-    Query<2> Q;
-    query_setup_fwd<2>(key, P, Q);
+    Query<KeyTraits<KW>::SW> Q;
+    query_setup_fwd<KW>(key, P, Q);
     R.r[0] = Q.q[1].s[0]; R.r[1] = Q.q[1].s[1];
     R.l = Q.ok ? Q.l : 0; R.s = Q.s; R.ok = Q.ok;
-    probe_masks(R);
+    R.nraw = KeyTraits<KW>::HASN ? Q.q[1].n[0] : 0ull;
     R.tab = L.ctab; R.nlook = 0; R.lead = false; R.served = false;
     R.ps[0] = 0; R.ps[1] = 0; R.ps[2] = 0;
+    if (KW == 6 && Q.ok && Q.l > 56) { R.l = 0; R.s = 0; probe_masks(R); return; }       // not served: the generic kernel's
+    probe_masks(R);
     if (!Q.ok) return;
+    if (KW == 6 && popc64(R.nraw) > P.maxmm) { R.served = true; return; }                // served: no alignment can exist
     const int np = round_np(P);
     if (piece_cut(Q.span, 1, np) >= L.kb) {                        // the shortest piece is the first: floor(span / np)
         R.nlook = np; R.served = true;
@@ -1332,6 +1338,20 @@ MG_HD void probe_lookup(const ProbeRead& R, const LibDev& L, int i, uint32_t& sl
     slot = R.tab.slot_off + b;
     b += R.tab.bits_off << 5;
 }
+// does the key of lookup i hold a read N?  (Then that piece / those blocks are not the exact ones: the lookup is left
+// out, as the generic matcher leaves out a piece that holds an N.)
+MG_HD bool probe_lookup_n(const ProbeRead& R, const LibDev& L, int i) {
+    const uint32_t bl = tab_blocks(R.tab);
+    if (bl == 0) {
+        const int ps = i == 0 ? R.ps[0] : (i == 1 ? R.ps[1] : R.ps[2]);
+        return ((R.nraw >> ps) & ones(L.kb)) != 0;
+    }
+    const uint32_t mask = scheme_shape(tab_m(R.tab), i);
+    uint64_t km = 0; int at = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int bj = blk(bl, j); if ((mask >> j) & 1) km |= ones(bj) << at; at += bj; }
+    return (R.nraw & km) != 0;
+}
 // may lookup i be left out, given the best alignment found so far (0 = none)?  Scheme: shape 0 has already found
 // every stratum-0 alignment.  Plain pieces: piece_needed's rule.
 MG_HD bool probe_needed(const ProbeRead& R, const RoundDev& P, int i, uint64_t score) {
@@ -1341,6 +1361,7 @@ MG_HD bool probe_needed(const ProbeRead& R, const RoundDev& P, int i, uint64_t s
 }
 // One entry against a read whose lookup started ps nt into it: false = no alignment, true = valid alignment (f, sm,
 // tm, w, ref set).  K = the looked-up window's length.  Forward and (mirrored) reverse entries are judged alike.
+template <bool HASN = false>
 MG_HD bool probe_verify(const RoundDev& P, const ProbeRead& R, int K, int ps, const PEnt& e,
                         int& f, int& sm, int& tm, uint32_t& w, uint32_t& ref) {
     // no N, no reference boundary inside the window: it reaches ps nt back from the lookup position and l - ps nt on
@@ -1352,7 +1373,9 @@ MG_HD bool probe_verify(const RoundDev& P, const ProbeRead& R, int K, int ps, co
     const uint64_t y0 = o >= 32 ? c1 : c0, y1 = o >= 32 ? c2 : c1, y2 = o >= 32 ? 0ull : c2;
     const uint64_t x0 = sh ? (y0 >> sh) | (y1 << (64 - sh)) : y0, x1 = sh ? (y1 >> sh) | (y2 << (64 - sh)) : y1;
     uint64_t d0 = x0 ^ R.r[0], d1 = x1 ^ R.r[1];
-    d0 = (d0 | (d0 >> 1)) & R.ml[0]; d1 = (d1 | (d1 >> 1)) & R.ml[1];
+    d0 = d0 | (d0 >> 1); d1 = d1 | (d1 >> 1);
+    if (HASN) { d0 |= spread32((uint32_t)R.nraw); d1 |= spread32((uint32_t)(R.nraw >> 32)); }      // a read N mismatches everything
+    d0 &= R.ml[0]; d1 &= R.ml[1];
     tm = popc64(d0) + popc64(d1);
     if (tm > P.maxmm) return false;
     sm = popc64(d0 & R.ms[0]) + popc64(d1 & R.ms[1]);
@@ -1389,16 +1412,18 @@ MG_HD void probe_record(ProbeBest& Bst, int sm, int tm, uint32_t w, int f, uint3
 MG_HD int tab_K(const TabDesc& t, const LibDev& L) { return tab_blocks(t) ? tab_W(t) : L.kb; }
 
 // Serial form of the probe path for one read: false = not served (ask the generic matcher).
+template <int KW>
 __host__ __device__ inline bool probe_one(const uint64_t* key, const LibDev& L, const RoundDev& P, ProbeBest& Bst) {
     const RoundSch RS = round_schemes(L, P);
     ProbeRead R;
-    probe_setup<ROUND_SCHEMES>(key, L, P, RS, R);
+    probe_setup<ROUND_SCHEMES, KW>(key, L, P, RS, R);
     Bst.score = 0; Bst.rmax = 0; Bst.rmin = 0; Bst.ref = 0;
     if (!R.ok) return true;                      // bowtie skips the read: served, no alignment
     if (!R.served) return false;
     const int K = tab_K(R.tab, L);
     for (int i = 0; i < R.nlook; ++i) {
         if (!probe_needed(R, P, i, Bst.score)) continue;
+        if (KW == 6 && probe_lookup_n(R, L, i)) continue;
         uint32_t slot, b; int ps;
         probe_lookup(R, L, i, slot, b, ps);
         if (tab_bits(R.tab) && !((L.sbits[b >> 5] >> (b & 31)) & 1)) continue;
@@ -1409,7 +1434,7 @@ __host__ __device__ inline bool probe_one(const uint64_t* key, const LibDev& L, 
         if (kind == 1 && hi - lo > (uint32_t)PROBE_MAX_LIST) return false;
         for (uint32_t c = lo; c < (kind == 2 ? lo + 1 : hi); ++c) {
             int f, sm, tm; uint32_t w, ref;
-            if (probe_verify(P, R, K, ps, kind == 2 ? e : load_pent(L.pent, c), f, sm, tm, w, ref)) probe_record(Bst, sm, tm, w, f, ref);
+            if (probe_verify<KW == 6>(P, R, K, ps, kind == 2 ? e : load_pent(L.pent, c), f, sm, tm, w, ref)) probe_record(Bst, sm, tm, w, f, ref);
         }
     }
     return true;
@@ -1540,9 +1565,9 @@ __host__ __device__ inline bool match_one(const uint64_t* key, const LibDev& L, 
             return true;
         }
     }
-    if (KW == 2 && probe_round(L, P)) {
+    if (probe_round(L, P)) {
         ProbeBest Bst;
-        if (probe_one(key, L, P, Bst)) {
+        if (probe_one<KW>(key, L, P, Bst)) {
             if (!Bst.score) return false;
             ref = (int32_t)Bst.ref;
             amb = (uint32_t)Bst.rmax != 0xFFFFFFFFu - (uint32_t)Bst.rmin;
@@ -1982,7 +2007,8 @@ template <int NS> struct ProbeQ { static constexpr int Q4 = NS >= 3 ? 768 : 320,
 MG_HD uint32_t chunk_meta(uint32_t owner, uint32_t cnt, int ps, int K) {
     return owner | ((cnt - 1) << 8) | ((uint32_t)ps << 14) | ((uint32_t)K << 20) | 0x80000000u;
 }
-template <int RN, int NS>
+// KW = 6: the 48-byte class (reads with N, or longer than 56 nt: those go on the fb list) through the same tables
+template <int RN, int NS, int KW = 2>
 __global__ void __launch_bounds__(PB, NS == 0 ? MG_PROBE_WAVES0 : (NS >= 3 ? MG_PROBE_WAVES3 : MG_PROBE_WAVES))
 k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round, int32_t* ann_ref, uint8_t* ann_amb,
               LibDev L, RoundDev P, RoundSch RS, unsigned long long* stats,
@@ -1993,6 +2019,7 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     __shared__ unsigned long long s_best[3 * PB];
     __shared__ uint64_t s_r0[PB], s_r1[PB];
     __shared__ uint32_t s_ls[PB];                // l | s << 8
+    __shared__ uint64_t s_nm[KW == 6 ? PB : 1];  // 48-byte class: the reads' N masks
     __shared__ uint32_t s_q4lo[PQ4], s_q4meta[PQ4], s_q64lo[PQ64], s_q64meta[PQ64];
     __shared__ uint32_t s_qn4, s_qn64, s_wcnt[2][PB / 64], s_base[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -2015,17 +2042,20 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     }
     const uint32_t i = i0 + tid;
     const uint32_t u = i < n ? (list ? list[i] : i) : EMPTY;
-    uint64_t k[2] = {0, 0};
+    uint64_t k[KW];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) k[w] = 0;
     uint8_t done_before = 0;
     if (u != EMPTY) {
         if (init) { ann_round[u] = 0; ann_ref[u] = -1; ann_amb[u] = 0; }       // as in k_match_round
         else if (!list) done_before = ann_round[u];
-        k[0] = ukeys[(uint64_t)u * 2]; k[1] = ukeys[(uint64_t)u * 2 + 1];
+#pragma unroll
+        for (int w = 0; w < KW; ++w) k[w] = ukeys[(uint64_t)u * KW + w];
     }
     const bool listed = u != EMPTY && done_before == 0;
     bool active = false;
     if (listed) {
-        const int len = key_len<2>(k);
+        const int len = key_len<KW>(k);
         active = !(P.len_lt && !(len < P.len_lt)) && !(P.len_gt && !(len > P.len_gt));
     }
     if (!__syncthreads_or(active) && !next_list) return;
@@ -2033,13 +2063,17 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     for (uint32_t j = tid; j < (uint32_t)PQ4; j += PB) s_q4meta[j] = 0;       // a chunk that is never written (queue overflow) stays empty
     for (uint32_t j = tid; j < (uint32_t)PQ64; j += PB) s_q64meta[j] = 0;
     if (tid == 0) { s_qn4 = 0; s_qn64 = 0; }
-    if (!active) { k[0] = 0; k[1] = 0; }                       // an empty read: ok comes out false
+    if (!active) {
+#pragma unroll
+        for (int w = 0; w < KW; ++w) k[w] = 0;                  // an empty read: ok comes out false
+    }
     ProbeRead R;
-    probe_setup<NS>(k, L, P, RS, R);
+    probe_setup<NS, KW>(k, L, P, RS, R);
     R.ok = R.ok && active;
     const bool run = R.ok && R.served;
     bool fb = R.ok && !R.served;                                // -> the generic kernel
     s_r0[tid] = R.r[0]; s_r1[tid] = R.r[1]; s_ls[tid] = (uint32_t)(R.l & 255) | ((uint32_t)(R.s & 255) << 8);
+    if (KW == 6) s_nm[tid] = R.nraw;
     __syncthreads();
 
     ProbeBest Bst; Bst.score = 0; Bst.rmax = 0; Bst.rmin = 0; Bst.ref = 0;      // what this thread finds itself
@@ -2050,7 +2084,7 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         const int kind = slot_kind(e, lo, hi);
         if (kind == 2) {
             int f, sm, tm; uint32_t w, ref;
-            if (probe_verify(P, R, K, ps, e, f, sm, tm, w, ref)) probe_record(Bst, sm, tm, w, f, ref);
+            if (probe_verify<KW == 6>(P, R, K, ps, e, f, sm, tm, w, ref)) probe_record(Bst, sm, tm, w, f, ref);
         } else if (kind == 1) {
             const uint32_t len = hi - lo;
             if (len > (uint32_t)PROBE_MAX_LIST) { fb = true; return; }
@@ -2086,6 +2120,7 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
             have[j] = run && !fb && i0 + j < R.nlook && probe_needed(R, P, i0 + j, Bst.score);
+            if (KW == 6) have[j] = have[j] && !probe_lookup_n(R, L, i0 + j);
             slot[j] = 0; b[j] = 0; ps[j] = 0;
             if (have[j]) probe_lookup<NS == 1>(R, L, i0 + j, slot[j], b[j], ps[j]);
             any = any || have[j];
@@ -2110,10 +2145,11 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         ProbeRead O;
         O.r[0] = s_r0[owner]; O.r[1] = s_r1[owner];
         O.l = (int)(s_ls[owner] & 255); O.s = (int)((s_ls[owner] >> 8) & 255);
+        O.nraw = KW == 6 ? s_nm[owner] : 0ull;
         const PEnt e = load_pent(L.pent, at);
         probe_masks(O);
         int f, sm, tm; uint32_t w, ref;
-        if (probe_verify(P, O, (int)((meta >> 20) & 31), (int)((meta >> 14) & 63), e, f, sm, tm, w, ref)) {
+        if (probe_verify<KW == 6>(P, O, (int)((meta >> 20) & 31), (int)((meta >> 14) & 63), e, f, sm, tm, w, ref)) {
             atomicMax(&s_best[owner], (unsigned long long)hit_score(sm, tm, w, f));
             atomicMax(&s_best[PB + owner], (unsigned long long)hit_kmax(sm, ref));
             atomicMax(&s_best[2 * PB + owner], (unsigned long long)hit_kmin(sm, ref));

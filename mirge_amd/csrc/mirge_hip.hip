@@ -1254,7 +1254,7 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
     const bool init = r == 0 || (r == 1 && ll);
     // the lists of the generic kernel's own leftovers (16-byte class, probe rounds): read whenever an earlier round wrote any
     const bool had_list = ll ? r >= 3 : r >= 2;
-    const uint32_t* fbs_in = (KW == 2 && had_list) ? C.fbs[(r + 1) & 1].as<uint32_t>() : (const uint32_t*)nullptr;
+    const uint32_t* fbs_in = had_list ? C.fbs[(r + 1) & 1].as<uint32_t>() : (const uint32_t*)nullptr;
     if (KW == 2 && lds_round(L, P)) {
         // the LDS path (kernels.h: k_lds_round): persistent blocks with the library's text in LDS, then the generic
         // kernel over the reads it handed on
@@ -1281,11 +1281,12 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
                            U_dev, (uint32_t)C.U);
         return;
     }
-    if (KW == 2 && probe_round(L, P)) {
+    if (probe_round(L, P)) {
         // the probe path (kernels.h: k_probe_round) for what the slot tables can serve, then the generic kernel over the
-        // reads it handed on
+        // reads it handed on.  The 48-byte class (a few ten thousand uniques) takes one instantiation for any number of schemes.
         const RoundSch RS = round_schemes(L, P);
-        auto kern = RS.n == 0 ? k_probe_round<RN, 0> : ((RS.n == 1 && blocks_equal(tab_blocks(RS.t[0]))) ? k_probe_round<RN, 1> : k_probe_round<RN, ROUND_SCHEMES>);      // (<.., 1>: one scheme, of equal blocks)
+        auto kern2 = RS.n == 0 ? k_probe_round<RN, 0> : ((RS.n == 1 && blocks_equal(tab_blocks(RS.t[0]))) ? k_probe_round<RN, 1> : k_probe_round<RN, ROUND_SCHEMES>);      // (<.., 1>: one scheme, of equal blocks)
+        auto kern = KW == 2 ? kern2 : k_probe_round<RN, ROUND_SCHEMES, 6>;
         const uint32_t grid = in.K > 1 ? in.K * (in.cap / PB) : (uint32_t)((UB + PB - 1) / PB);
         const uint32_t cap_out = (grid + LIST_K - 1) / LIST_K * PB;          // blocks that share a sub-list x what each can append
         ListOut out{nullptr, nullptr, 0, 0};
@@ -1295,7 +1296,7 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
                            L, P, RS, c->d_stats + (size_t)r * STAT_WORDS, in, out,
                            C.fb.as<uint32_t>(), C.fb_n + r, init, U_dev, (uint32_t)C.U);
         // (a small grid: its blocks stride over the lists, whose lengths -- usually a handful -- only the device knows)
-        hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)std::min<uint64_t>((UB + MB - 1) / MB, 512)), dim3(MB), 0, C.st,
+        hipLaunchKernelGGL((k_match_round<KW, RN>), dim3((uint32_t)std::min<uint64_t>((UB + MatchTile<KW>::N - 1) / MatchTile<KW>::N, 512)), dim3(MB), 0, C.st,
                            C.ukeys.as<uint64_t>(), (uint32_t)UB, C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(),
                            C.ann_amb.as<uint8_t>(), L, P, thr, c->d_stats + (size_t)r * STAT_WORDS,
                            ListIn{C.fb.as<uint32_t>(), C.fb_n + r, 1, 0}, fbs_in, (const unsigned long long*)(C.fbs_n + r),
@@ -1436,18 +1437,17 @@ int annotate(mirge_ctx* c) {
         HIPCHK(c, C.ann_amb.ensure(U, false, 0, c->st));
         HIPCHK(c, C.act[0].ensure((U + (size_t)LIST_K * 2 * PB) * 4, false, 0, c->st));      // (a split list: LIST_K sub-lists, each rounded up to whole tiles, then to whole blocks)
         HIPCHK(c, C.act[1].ensure((U + (size_t)LIST_K * 2 * PB) * 4, false, 0, c->st));
-        if (k == 0) {
-            HIPCHK(c, C.fb.ensure(U * 4, false, 0, c->st));
-            HIPCHK(c, C.fbs[0].ensure(U * 4, false, 0, c->st));
-            HIPCHK(c, C.fbs[1].ensure(U * 4, false, 0, c->st));
-        }
+        HIPCHK(c, C.fb.ensure(U * 4, false, 0, c->st));
+        HIPCHK(c, C.fbs[0].ensure(U * 4, false, 0, c->st));
+        HIPCHK(c, C.fbs[1].ensure(U * 4, false, 0, c->st));
         for (auto& f : C.lf) f = Class::ListFmt{};
     }
     int M = (int)c->libs[MIRGE_LIB_MIRNA].names.size(), S = c->S;
     size_t qn = std::max<size_t>((size_t)M * S, 1);
     const size_t w_stats = MIRGE_MAX_ROUNDS * STAT_WORDS, w_cat = (size_t)5 * S, w_len = (size_t)LEN_BINS * S, w_tu = (size_t)S;
     const size_t w_act = (size_t)(MIRGE_MAX_ROUNDS + 1) * LIST_K * LIST_NSTRIDE;        // list length words of one key class: LIST_K per round, 128 B apart
-    const size_t w_out = w_stats + 2 * qn + w_cat + w_len + w_tu, w_all = w_out + 2 * w_act + MIRGE_MAX_ROUNDS + (MIRGE_MAX_ROUNDS + 1);
+    const size_t w_fb = MIRGE_MAX_ROUNDS + (MIRGE_MAX_ROUNDS + 1);                        // per class: fb list lengths, leftover-list lengths
+    const size_t w_out = w_stats + 2 * qn + w_cat + w_len + w_tu, w_all = w_out + 2 * w_act + 2 * w_fb;
     HIPCHK(c, c->state.ensure(w_all * 8, false, 0, c->st));
     if (c->h_state_cap < w_out) {
         if (c->h_state) (void)hipHostFree(c->h_state);
@@ -1459,8 +1459,8 @@ int annotate(mirge_ctx* c) {
     c->d_quant = c->d_stats + w_stats; c->d_iscan = c->d_quant + qn; c->d_cat = c->d_iscan + qn;
     c->d_len = c->d_cat + w_cat; c->d_tu = c->d_len + w_len;
     c->cls[0].act_n = c->d_tu + w_tu; c->cls[1].act_n = c->cls[0].act_n + w_act;
-    c->cls[0].fb_n = c->cls[1].act_n + w_act;
-    c->cls[0].fbs_n = c->cls[0].fb_n + MIRGE_MAX_ROUNDS; c->cls[1].fbs_n = c->cls[0].fbs_n;       // (the 48-byte class has no such lists: its launches get none)
+    c->cls[0].fb_n = c->cls[1].act_n + w_act; c->cls[0].fbs_n = c->cls[0].fb_n + MIRGE_MAX_ROUNDS;
+    c->cls[1].fb_n = c->cls[0].fb_n + w_fb; c->cls[1].fbs_n = c->cls[1].fb_n + MIRGE_MAX_ROUNDS;
     HIPCHK(c, hipMemsetAsync(c->state.p, 0, w_all * 8, c->st));
     hipEvent_t e0 = c->ev_t[0], e1 = c->ev_t[1], e2 = c->ev_t[2];
     if (c->timing) HIPCHK(c, hipEventRecord(e0, c->st));
