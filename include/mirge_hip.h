@@ -244,6 +244,50 @@ int32_t     mirge_export_counts(mirge_ctx*, uint64_t* uid, uint32_t* sample, uin
 int32_t     mirge_write_tables(mirge_ctx*, const char* merges_csv, const char* output_dir, const char* const* sample_names,
                                uint64_t* mirna_reads_filtered, uint64_t* mirna_uniq_filtered);
 
+/* ---- many sample files at once (the per-sample loop of runQuantitationPipeline, miRge.pl:243-266) -----------------
+ * files[i] -> samples[i], collapsed in that order; up to 16 host threads read / inflate files ahead of the device (a
+ * gzip stream is serial, but different files do not wait for each other: a batch of .gz samples inflates at the pace
+ * of the host's cores, not of one).  adapter = NULL: trimmed files (as mirge_collapse_fastq); else raw files through
+ * the trimming step (as mirge_collapse_raw_fastq).  total_reads / trimmed_reads / phred (nullable): per file. */
+int32_t     mirge_collapse_fastq_batch(mirge_ctx*, int32_t n, const char* const* files, const int32_t* samples, const char* adapter,
+                                       int32_t trim5, int32_t trim3, uint64_t* total_reads, uint64_t* trimmed_reads, int32_t* phred);
+
+/* ---- multi-GPU inside the library (no counterpart in the single-process reference, whose only
+ * parallelism is --threads forwarded to bowtie, miRge.pl:327) ---------------------------------------------------
+ * A group = one context per GPU in this process, driven by host threads.  mirge_group_annotate() is
+ *   merge of the unique tables by key owner (mirge_shard_export / import around ONE all-to-all per key class:
+ *   grouped ncclSend / ncclRecv, GPU to GPU) -> the cascade on every rank over the sequences it owns -> ONE
+ *   ncclAllReduce(ncclUint64, ncclSum) of the flat count buffer;
+ * afterwards every sequence lives on exactly one rank, and counts / round statistics are those of the one-GPU run.
+ * RCCL is loaded with dlopen("librccl.so.1") at the first group; the library does not link it.
+ * mirge_group_open: devices 0 .. n_gpus-1.  mirge_group_open_ex: any devices; MIRGE_GROUP_HOST_STAGED = both exchanges
+ * through host memory instead of RCCL, so that several ranks can share one device (how the N > 1 code is rehearsed
+ * on a one-GPU box).  mirge_group_ctx(rank) is a borrowed context for the per-rank queries (library names, per-unique
+ * export of what that rank owns).  Calls on one group are serial, like a context's. */
+typedef struct mirge_group mirge_group;
+#define MIRGE_GROUP_HOST_STAGED 1u
+mirge_group* mirge_group_open(const char* species_dir, int32_t n_samples, int32_t n_gpus);
+mirge_group* mirge_group_open_ex(const char* species_dir, int32_t n_samples, int32_t n_ranks, const int32_t* devices, uint32_t flags);
+void        mirge_group_close(mirge_group*);
+const char* mirge_group_last_error(const mirge_group*);       /* NULL: why the last open on this thread failed */
+int32_t     mirge_group_size(const mirge_group*);
+mirge_ctx*  mirge_group_ctx(mirge_group*, int32_t rank);
+int32_t     mirge_group_reset(mirge_group*, int32_t n_samples);
+int32_t     mirge_group_load_library_mem(mirge_group*, int32_t lib, int32_t n, const char* names, const char* seqs, const uint64_t* offs);
+/* one sample's reads: rank r takes the contiguous chunk [n r / W, n (r + 1) / W) */
+int32_t     mirge_group_collapse_seqs(mirge_group*, const char* seqs, const uint64_t* offs, uint64_t n, int32_t sample);
+/* many sample files: file i goes to rank i mod W as a whole; arguments as mirge_collapse_fastq_batch */
+int32_t     mirge_group_collapse_fastq_batch(mirge_group*, int32_t n, const char* const* files, const int32_t* samples, const char* adapter,
+                                             int32_t trim5, int32_t trim3, uint64_t* total_reads, uint64_t* trimmed_reads, int32_t* phred);
+int32_t     mirge_group_annotate(mirge_group*);                /* replaces runAnnotationPipeline + summarize's sums, miRge.pl:321-372, 465-493 */
+int32_t     mirge_group_counts(mirge_group*, const uint64_t** quant, const uint64_t** iscan, const uint64_t** category,
+                               const uint64_t** len_hist, const uint64_t** trimmed_uniq);
+int32_t     mirge_group_round_stats(const mirge_group*, int32_t round, uint64_t* processed, uint64_t* aligned, double* seconds);
+uint64_t    mirge_group_n_unique(const mirge_group*);
+int32_t     mirge_group_write_tables(mirge_group*, const char* merges_csv, const char* output_dir, const char* const* sample_names,
+                                     uint64_t* mirna_reads_filtered, uint64_t* mirna_uniq_filtered);
+int32_t     mirge_group_timing(const mirge_group*, double* merge_ms, double* allreduce_ms);
+
 /* ---- timing -------------------------------------------------------------- */
 /* Device time (HIP events on the library's stream) spent in the last
  * mirge_collapse_* call / the last mirge_annotate() + count-vector pass, ms. */

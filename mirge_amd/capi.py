@@ -30,6 +30,9 @@ EXPORTS = [
     "mirge_verb_export_size", "mirge_verb_export", "mirge_verb_clear", "mirge_verb_import",
     "mirge_n_counts", "mirge_export_counts", "mirge_last_timing", "mirge_kernel_times", "mirge_set_kernel_timing", "mirge_write_tables",
     "mirge_collapse_keys16_noalloc",
+    "mirge_collapse_fastq_batch", "mirge_group_open", "mirge_group_open_ex", "mirge_group_close", "mirge_group_last_error", "mirge_group_size",
+    "mirge_group_ctx", "mirge_group_reset", "mirge_group_load_library_mem", "mirge_group_collapse_seqs", "mirge_group_collapse_fastq_batch",
+    "mirge_group_annotate", "mirge_group_counts", "mirge_group_round_stats", "mirge_group_n_unique", "mirge_group_write_tables", "mirge_group_timing",
 ]
 
 
@@ -113,8 +116,35 @@ def load():
     L.mirge_last_timing.argtypes = [vp] + [C.POINTER(C.c_double)] * 3
     L.mirge_kernel_times.argtypes = [vp, vp, vp, vp, i32]
     L.mirge_set_kernel_timing.argtypes = [vp, i32]
+    L.mirge_collapse_fastq_batch.argtypes = [vp, i32, vp, vp, C.c_char_p, i32, i32, vp, vp, vp]
+    L.mirge_group_open.restype = vp; L.mirge_group_open.argtypes = [C.c_char_p, i32, i32]
+    L.mirge_group_open_ex.restype = vp; L.mirge_group_open_ex.argtypes = [C.c_char_p, i32, i32, vp, u32]
+    L.mirge_group_close.restype = None; L.mirge_group_close.argtypes = [vp]
+    L.mirge_group_last_error.restype = C.c_char_p; L.mirge_group_last_error.argtypes = [vp]
+    L.mirge_group_size.argtypes = [vp]
+    L.mirge_group_ctx.restype = vp; L.mirge_group_ctx.argtypes = [vp, i32]
+    L.mirge_group_reset.argtypes = [vp, i32]
+    L.mirge_group_load_library_mem.argtypes = [vp, i32, i32, C.c_char_p, vp, vp]
+    L.mirge_group_collapse_seqs.argtypes = [vp, vp, vp, u64, i32]
+    L.mirge_group_collapse_fastq_batch.argtypes = [vp, i32, vp, vp, C.c_char_p, i32, i32, vp, vp, vp]
+    L.mirge_group_annotate.argtypes = [vp]
+    L.mirge_group_counts.argtypes = [vp] + [C.POINTER(C.POINTER(u64))] * 5
+    L.mirge_group_round_stats.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
+    L.mirge_group_n_unique.restype = u64; L.mirge_group_n_unique.argtypes = [vp]
+    L.mirge_group_write_tables.argtypes = [vp, C.c_char_p, C.c_char_p, vp, vp, vp]
+    L.mirge_group_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = L
     return L
+
+
+def _batch(fn, obj, paths, samples, adapter, trim5, trim3):
+    n = len(paths)
+    arr = (C.c_char_p * max(n, 1))(*[p.encode() for p in paths])
+    smp = np.ascontiguousarray(samples, dtype=np.int32)
+    tot = np.zeros(max(n, 1), dtype=np.uint64); kept = np.zeros(max(n, 1), dtype=np.uint64); ph = np.zeros(max(n, 1), dtype=np.int32)
+    obj._chk(fn(obj.h, n, C.cast(arr, C.c_void_p), smp.ctypes.data, adapter.encode() if adapter is not None else None, trim5, trim3,
+                tot.ctypes.data, kept.ctypes.data, ph.ctypes.data))
+    return tot[:n], kept[:n], ph[:n]
 
 
 class Context:
@@ -194,6 +224,10 @@ class Context:
         n = C.c_uint64(0)
         self._chk(self.L.mirge_collapse_fastq(self.h, path.encode(), sample, C.byref(n)))
         return n.value
+
+    def collapse_fastq_batch(self, paths, samples, adapter=None, trim5=0, trim3=0):
+        """Many sample files (plain or .gz) in order, host threads reading / inflating ahead -> (total[n], kept[n], phred[n])."""
+        return _batch(self.L.mirge_collapse_fastq_batch, self, paths, samples, adapter, trim5, trim3)
 
     # ---- multi-GPU exchange step (include/mirge_hip.h: mirge_shard_*)
     def shard_export_sizes(self, world):
@@ -377,3 +411,110 @@ class Context:
         names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); by = (C.c_uint64 * cap)()
         n = self._chk(self.L.mirge_kernel_times(self.h, names, ms, by, cap))
         return {names[i].decode(): (ms[i], by[i]) for i in range(min(n, cap))}
+
+
+GROUP_HOST_STAGED = 1
+
+
+class _Borrowed(Context):
+    """A rank's context inside a Group: same methods, owned (and closed) by the group."""
+
+    def __init__(self, L, h, S):
+        self.L, self.h, self.S = L, h, S
+
+    def close(self):
+        self.h = None
+
+    __del__ = close
+
+
+class Group:
+    """One mirge_group: a context per GPU inside the library, merge of the unique tables + count all-reduce over RCCL
+    (include/mirge_hip.h: mirge_group_*).  flags=GROUP_HOST_STAGED: exchanges through host memory, ranks may share a device."""
+
+    def __init__(self, species_dir=None, n_samples=1, n_ranks=1, devices=None, flags=0):
+        self.L = load()
+        self.S = n_samples
+        dv = np.ascontiguousarray(devices, dtype=np.int32) if devices is not None else None
+        self.h = self.L.mirge_group_open_ex(species_dir.encode() if species_dir else None, n_samples, n_ranks,
+                                            dv.ctypes.data if dv is not None else None, flags)
+        if not self.h:
+            raise MirgeError(-3, self.L.mirge_group_last_error(None).decode())
+        self.world = n_ranks
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mirge_group_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise MirgeError(rc, self.L.mirge_group_last_error(self.h).decode())
+        return rc
+
+    def ctx(self, rank):
+        return _Borrowed(self.L, self.L.mirge_group_ctx(self.h, rank), self.S)
+
+    def reset(self, n_samples=None):
+        if n_samples is not None:
+            self.S = n_samples
+        self._chk(self.L.mirge_group_reset(self.h, self.S))
+
+    def load_library(self, lib, names, text, offs):
+        text = np.ascontiguousarray(text, dtype=np.uint8); offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        blob = ("\0".join(names) + "\0").encode()
+        self._chk(self.L.mirge_group_load_library_mem(self.h, lib, len(names), blob, text.ctypes.data, offs.ctypes.data))
+
+    def collapse_seqs(self, reads, sample, lens):
+        lens = np.asarray(lens, dtype=np.int64)
+        mask = np.arange(reads.shape[1])[None, :] < lens[:, None]
+        text = np.ascontiguousarray(reads[mask])
+        offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=offs[1:])
+        self._chk(self.L.mirge_group_collapse_seqs(self.h, text.ctypes.data, offs.ctypes.data, len(lens), sample))
+
+    def collapse_fastq_batch(self, paths, samples, adapter=None, trim5=0, trim3=0):
+        return _batch(self.L.mirge_group_collapse_fastq_batch, self, paths, samples, adapter, trim5, trim3)
+
+    def annotate(self):
+        self._chk(self.L.mirge_group_annotate(self.h))
+
+    def counts(self):
+        ptrs = [C.POINTER(C.c_uint64)() for _ in range(5)]
+        self._chk(self.L.mirge_group_counts(self.h, *[C.byref(p) for p in ptrs]))
+        M, S = self.ctx(0).lib_size(LIB_MIRNA), self.S
+        shp = [(M, S), (M, S), (5, S), (MAX_READ_LEN + 1, S), (S,)]
+        out = []
+        for p, sh in zip(ptrs, shp):
+            n = int(np.prod(sh))
+            out.append(np.ctypeslib.as_array(p, shape=(max(n, 1),))[:n].reshape(sh).copy())
+        return dict(quant=out[0], iscan=out[1], cat=out[2], lenhist=out[3], tuniq=out[4])
+
+    def round_stats(self, rnd):
+        p = C.c_uint64(); a = C.c_uint64(); s = C.c_double()
+        self._chk(self.L.mirge_group_round_stats(self.h, rnd, C.byref(p), C.byref(a), C.byref(s)))
+        return p.value, a.value, s.value
+
+    def n_unique(self):
+        return int(self.L.mirge_group_n_unique(self.h))
+
+    def timing(self):
+        a = C.c_double(); b = C.c_double()
+        self._chk(self.L.mirge_group_timing(self.h, C.byref(a), C.byref(b)))
+        return dict(merge_ms=a.value, allreduce_ms=b.value)
+
+    def write_tables(self, merges_csv, output_dir, sample_names):
+        S = len(sample_names)
+        arr = (C.c_char_p * S)(*[n.encode() for n in sample_names])
+        tot = np.zeros(S, dtype=np.uint64); uq = np.zeros(S, dtype=np.uint64)
+        self._chk(self.L.mirge_group_write_tables(self.h, merges_csv.encode() if merges_csv else None, output_dir.encode(), arr,
+                                                  tot.ctypes.data, uq.ctypes.data))
+        return tot, uq

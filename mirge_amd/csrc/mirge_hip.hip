@@ -2288,3 +2288,5 @@ int32_t mirge_kernel_times(const mirge_ctx* c, const char** names, double* ms, u
 }
 
 }  // extern "C"
+
+#include "group.h"
