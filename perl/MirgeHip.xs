@@ -9,6 +9,7 @@
 #include "../include/mirge_hip.h"
 
 typedef mirge_ctx* MirgeHip;
+typedef mirge_group* MirgeHipGroup;
 
 MODULE = MirgeHip    PACKAGE = MirgeHip    PREFIX = mirge_
 
@@ -161,3 +162,77 @@ mirge_export_bulk(ctx)
         EXTEND(SP, 11);
         mPUSHu((UV)U); mPUSHu((UV)stride); mPUSHs(seqs); mPUSHs(lens); mPUSHs(rnd); mPUSHs(ref); mPUSHs(amb);
         mPUSHu((UV)nnz); mPUSHs(uid); mPUSHs(smp); mPUSHs(cnt);
+
+# ---- several GPUs inside the library (include/mirge_hip.h: mirge_group_*); group_ctx() is rank r's context, borrowed:
+# the per-rank accessors above (lib_short_name, export_bulk ...) take it, close() must not be called on it
+
+MirgeHipGroup
+mirge_group_open(species_dir, n_samples, n_gpus, host_staged = 0, device = 0)
+        const char* species_dir
+        int n_samples
+        int n_gpus
+        int host_staged
+        int device
+    PREINIT:
+        int32_t dev[64]; int r;
+    CODE:
+        if (n_gpus < 1 || n_gpus > 64) croak("MirgeHip::group_open: between 1 and 64 GPUs");
+        for (r = 0; r < n_gpus; ++r) dev[r] = host_staged ? device : r;
+        RETVAL = mirge_group_open_ex(species_dir, n_samples, n_gpus, dev, host_staged ? MIRGE_GROUP_HOST_STAGED : 0u);
+        if (!RETVAL) croak("MirgeHip::group_open: %s", mirge_group_last_error(NULL));
+    OUTPUT:
+        RETVAL
+
+void
+mirge_group_close(g)
+        MirgeHipGroup g
+
+int
+mirge_group_size(g)
+        MirgeHipGroup g
+
+MirgeHip
+mirge_group_ctx(g, rank)
+        MirgeHipGroup g
+        int rank
+    CODE:
+        RETVAL = mirge_group_ctx(g, rank);
+        if (!RETVAL) croak("MirgeHip::group_ctx: rank out of range");
+    OUTPUT:
+        RETVAL
+
+void
+mirge_group_collapse_fastq_batch(g, paths, adapter, trim5, trim3)
+        MirgeHipGroup g
+        AV* paths
+        SV* adapter
+        int trim5
+        int trim3
+    PREINIT:
+        int n, i; const char** fp; int32_t* smp; uint64_t *tot, *kept; int32_t* ph; int rc;
+    PPCODE:
+        /* file i is sample i; adapter undef = trimmed files.  Returns (total_0, kept_0, phred_0, total_1, ...) */
+        n = (int)(av_len(paths) + 1);
+        Newx(fp, n ? n : 1, const char*); Newx(smp, n ? n : 1, int32_t); Newx(tot, n ? n : 1, uint64_t); Newx(kept, n ? n : 1, uint64_t); Newx(ph, n ? n : 1, int32_t);
+        for (i = 0; i < n; ++i) { SV** e = av_fetch(paths, i, 0); fp[i] = e ? SvPV_nolen(*e) : ""; smp[i] = i; tot[i] = kept[i] = 0; ph[i] = 33; }
+        rc = mirge_group_collapse_fastq_batch(g, n, fp, smp, SvOK(adapter) ? SvPV_nolen(adapter) : NULL, trim5, trim3, tot, kept, ph);
+        if (rc == MIRGE_OK) { EXTEND(SP, 3 * n); for (i = 0; i < n; ++i) { mPUSHu((UV)tot[i]); mPUSHu((UV)kept[i]); mPUSHi((IV)ph[i]); } }
+        Safefree(fp); Safefree(smp); Safefree(tot); Safefree(kept); Safefree(ph);
+        if (rc != MIRGE_OK) croak("MirgeHip::group_collapse_fastq_batch: %s", mirge_group_last_error(g));
+
+void
+mirge_group_annotate(g)
+        MirgeHipGroup g
+    CODE:
+        if (mirge_group_annotate(g) != MIRGE_OK) croak("MirgeHip::group_annotate: %s", mirge_group_last_error(g));
+
+void
+mirge_group_round_stats(g, round)
+        MirgeHipGroup g
+        int round
+    PREINIT:
+        uint64_t p = 0, a = 0; double s = 0;
+    PPCODE:
+        if (mirge_group_round_stats(g, round, &p, &a, &s) != MIRGE_OK) croak("MirgeHip::group_round_stats: bad round");
+        EXTEND(SP, 3);
+        mPUSHu((UV)p); mPUSHu((UV)a); mPUSHn(s);

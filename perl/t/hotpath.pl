@@ -13,9 +13,9 @@ use Getopt::Long;
 use Time::HiRes qw(time);
 use MirgeHip;
 
-my ($species, $out, $adapter, $names, $trim5, $trim3) = (undef, undef, undef, undef, 0, 0);
+my ($species, $out, $adapter, $names, $trim5, $trim3, $gpus, $staged) = (undef, undef, undef, undef, 0, 0, 0, 0);
 GetOptions('species=s' => \$species, 'out=s' => \$out, 'adapter=s' => \$adapter, 'names=s' => \$names,
-           'trim5=i' => \$trim5, 'trim3=i' => \$trim3) or die "bad options\n";
+           'trim5=i' => \$trim5, 'trim3=i' => \$trim3, 'gpus=i' => \$gpus, 'host-staged' => \$staged) or die "bad options\n";
 my @fastq = @ARGV;
 $species = shift @fastq unless defined $species;
 my $S = scalar(@fastq);
@@ -23,10 +23,18 @@ die "usage: hotpath.pl <species_dir> <fastq> ...\n" unless defined $species && $
 my $T0 = time; my $t = $T0;
 sub stage { my ($n) = @_; my $now = time; printf STDERR "[hotpath] %s %.3f\n", $n, $now - $t; $t = $now; }
 
-my $ctx = MirgeHip::open($species, $S, 0);                           # the four libraries + their seed indexes
+# --gpus N (with --out): one context per GPU inside the library (MirgeHip::group_*: whole sample files per GPU, unique tables
+# merged by key owner over RCCL, one all-reduce of the count vectors); --host-staged: the N ranks share device 0 (rehearsal)
+my $grp = $gpus > 0 ? MirgeHip::group_open($species, $S, $gpus, $staged ? 1 : 0, 0) : undef;
+my $ctx = defined $grp ? MirgeHip::group_ctx($grp, 0) : MirgeHip::open($species, $S, 0);     # the four libraries + their seed indexes
 stage('open') if defined $out;
 my @trimmedReads;
-for (my $i = 0; $i < $S; $i++) {
+if (defined $grp) {
+    die "--gpus needs --out\n" unless defined $out;
+    my @r = MirgeHip::group_collapse_fastq_batch($grp, \@fastq, $adapter, $trim5, $trim3);
+    $trimmedReads[$_] = $r[3 * $_ + 1] for (0 .. $S - 1);
+}
+for (my $i = 0; $i < $S && !defined $grp; $i++) {
     if (defined $adapter) {                                          # trimRaw + cutadapt -u + quantReads, miRge.pl:259-262
         my ($total, $kept, $phred) = MirgeHip::collapse_raw_fastq($ctx, $fastq[$i], $i, $adapter, $trim5, $trim3);
         $trimmedReads[$i] = $kept;
@@ -36,7 +44,8 @@ for (my $i = 0; $i < $S; $i++) {
     print "trimmedReads\t$i\t$trimmedReads[$i]\n" unless defined $out;
 }
 stage('collapse') if defined $out;
-MirgeHip::annotate($ctx);                                            # runAnnotationPipeline, miRge.pl:321-372
+if (defined $grp) { MirgeHip::group_annotate($grp); } else {
+MirgeHip::annotate($ctx); }                                          # runAnnotationPipeline, miRge.pl:321-372
 stage('annotate') if defined $out;
 my ($quant, $iscan, $cat, $lenhist, $tuniq) = MirgeHip::counts($ctx, $S);   # summarize, miRge.pl:453-494
 my $M = MirgeHip::lib_size($ctx, 0);
@@ -109,24 +118,27 @@ for my $n (keys %mirHash) { for (my $i = 0; $i < $S; $i++) { $mirHash{$n}{quant}
 for my $n (keys %mirHash) { for (my $i = 0; $i < $S; $i++) { if (($mirHash{$n}{quant}[$i] // 0) > 0) { $tot[$i] += $mirHash{$n}{quant}[$i]; $uq[$i]++; } } }
 stage('summarize_merge_filter');
 
-my ($U, $stride, $bseqs, $blens, $brnd, $bref, $bamb, $nnz, $buid, $bsmp, $bcnt) = MirgeHip::export_bulk($ctx);   # ONE call for all uniques
-stage('export_bulk');
-my @lens = unpack("S*", $blens); my @rnd = unpack("c*", $brnd); my @ref = unpack("l*", $bref);
-my @uid = unpack("Q*", $buid); my @smp = unpack("L*", $bsmp); my @cnt = unpack("L*", $bcnt);
-my @row = map { [ (0) x $S ] } (1 .. $U);
-$row[$uid[$_]][$smp[$_]] += $cnt[$_] for (0 .. $nnz - 1);
-stage('unpack');
 mkdir $out unless -d $out;
 my $head = "uniqueSequence,annotFlag,exact miRNA,hairpin miRNA,non miRNA/mRNA RNA,mRNA,isomiR miRNA," . join(",", @sampleNames) . "\n";
 open(my $fm, '>', "$out/mapped.csv") or die "cannot write $out/mapped.csv\n";
 open(my $fu, '>', "$out/unmapped.csv") or die "cannot write $out/unmapped.csv\n";
 print $fm $head; print $fu $head;
-for (my $u = 0; $u < $U; $u++) {
-    my $r = $rnd[$u];
-    my @ann = ('') x 5;
-    $ann[$r - 1] = $shortNames[$libOfRound[$r - 1]][$ref[$u]] if $r > 0;
-    my $line = join(",", substr($bseqs, $u * $stride, $lens[$u]), $r > 0 ? 1 : 0, @ann, @{$row[$u]});
-    if ($r > 0) { print $fm $line, ",\n"; } else { print $fu $line, "\n"; }
+for my $rank (0 .. (defined $grp ? MirgeHip::group_size($grp) : 1) - 1) {      # (after the merge every sequence lives on one rank)
+    my $rc = defined $grp ? MirgeHip::group_ctx($grp, $rank) : $ctx;
+    my ($U, $stride, $bseqs, $blens, $brnd, $bref, $bamb, $nnz, $buid, $bsmp, $bcnt) = MirgeHip::export_bulk($rc);   # ONE call for all uniques
+    stage('export_bulk');
+    my @lens = unpack("S*", $blens); my @rnd = unpack("c*", $brnd); my @ref = unpack("l*", $bref);
+    my @uid = unpack("Q*", $buid); my @smp = unpack("L*", $bsmp); my @cnt = unpack("L*", $bcnt);
+    my @row = map { [ (0) x $S ] } (1 .. $U);
+    $row[$uid[$_]][$smp[$_]] += $cnt[$_] for (0 .. $nnz - 1);
+    stage('unpack');
+    for (my $u = 0; $u < $U; $u++) {
+        my $r = $rnd[$u];
+        my @ann = ('') x 5;
+        $ann[$r - 1] = $shortNames[$libOfRound[$r - 1]][$ref[$u]] if $r > 0;
+        my $line = join(",", substr($bseqs, $u * $stride, $lens[$u]), $r > 0 ? 1 : 0, @ann, @{$row[$u]});
+        if ($r > 0) { print $fm $line, ",\n"; } else { print $fu $line, "\n"; }
+    }
 }
 close $fm; close $fu;
 open(my $fc, '>', "$out/miR.Counts.csv") or die; open(my $fr, '>', "$out/miR.RPM.csv") or die;
@@ -138,5 +150,5 @@ for my $n (sort keys %mirHash) {
 }
 close $fc; close $fr;
 stage('tables');
-MirgeHip::close($ctx);
+if (defined $grp) { MirgeHip::group_close($grp); } else { MirgeHip::close($ctx); }
 printf STDERR "[hotpath] total %.3f\n", time - $T0;

@@ -110,6 +110,26 @@ def test_batch_cli_writes_the_reference_tables(tmp_path, name):
     assert bad.returncode == 1 and "cannot find" in bad.stderr
 
 
+@pytest.mark.parametrize("args", [["--gpus", "1"], ["--gpus", "3", "--host-staged"]])
+def test_batch_cli_over_a_group_of_gpus(tmp_path, args):
+    """tools/mirge-annotate --gpus N: the same tables through mirge_group_* -- one rank over RCCL, and three logical ranks
+    on one device with the exchanges staged through host memory (whole sample files per rank)."""
+    import re
+    case = util.golden_case("synth_tiny")
+    out = str(tmp_path / "out")
+    r = subprocess.run([os.path.join(ROOT, "tools", "mirge-annotate"), "--species", case["species"], "--SampleFiles", ",".join(case["fastqs"]),
+                        "--SampleNames=" + ",".join(case["names"]), "--outputDir", out] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exp = case["expected"]
+    for f in ("miR.Counts.csv", "miR.RPM.csv"):
+        assert open(os.path.join(out, f)).read() == open(os.path.join(exp, f)).read(), f
+    for f in ("mapped.csv", "unmapped.csv"):
+        assert util.rows(os.path.join(out, f)) == util.rows(os.path.join(exp, f)), f
+    aligned = [int(x) for x in re.findall(r"readsAligned (\d+)", r.stdout)]
+    assert aligned == [case["stats"]["annotStats"][k]["readsAligned"] for k in range(5)]
+    assert "merge of the unique tables" in r.stdout
+
+
 @pytest.mark.parametrize("name", util.golden_cases())
 def test_perl_full_run_writes_the_reference_tables(tmp_path, name):
     """perl/t/hotpath.pl --out: the XS call sequence of INTEGRATION.md with ONE bulk export (MirgeHip::export_bulk) instead of
@@ -128,3 +148,20 @@ def test_perl_full_run_writes_the_reference_tables(tmp_path, name):
     for f in ("mapped.csv", "unmapped.csv"):
         assert util.rows(os.path.join(out, f)) == util.rows(os.path.join(exp, f)), f
     assert "[hotpath] export_bulk" in r.stderr
+
+
+def test_perl_full_run_over_a_group_of_gpus(tmp_path):
+    """The same Perl run with MirgeHip::group_* (--gpus 2 --host-staged: two logical ranks on the box's one GPU, whole
+    sample files per rank, merge + all-reduce inside the library): the reference's tables."""
+    if not shutil.which("perl") or not os.path.exists(os.path.join(ROOT, "perl", "auto", "MirgeHip", "MirgeHip.so")):
+        pytest.skip("perl binding not built")
+    case = util.golden_case("synth_isomir")
+    out = str(tmp_path / "out")
+    r = subprocess.run(["perl", "-I" + os.path.join(ROOT, "perl"), os.path.join(ROOT, "perl", "t", "hotpath.pl"), "--species", case["species"],
+                        "--out", out, "--names", ",".join(case["names"]), "--gpus", "2", "--host-staged"] + case["fastqs"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exp = case["expected"]
+    for f in ("miR.Counts.csv", "miR.RPM.csv"):
+        assert open(os.path.join(out, f)).read() == open(os.path.join(exp, f)).read(), f
+    for f in ("mapped.csv", "unmapped.csv"):
+        assert util.rows(os.path.join(out, f)) == util.rows(os.path.join(exp, f)), f
