@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=1_000_000)
     ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end legs: FASTQ file -> count vectors (0 = skip)")
     ap.add_argument("--realistic-reads", type=int, default=20_000_000, help="reads of the extra line at the reference's published redundancy (0 = skip)")
+    ap.add_argument("--repeats-reads", type=int, default=10_000_000, help="reads of the extra line against repeat-rich libraries (0 = skip)")
     ap.add_argument("--perl-reads", type=int, default=1_000_000, help="raw reads of the e2e_perl leg, BASELINE.json configs[0] (0 = skip)")
     args = ap.parse_args()
 
@@ -395,6 +396,49 @@ def main():
                             "note": "class proportions and redundancy of docs/miRge/miRge.exampleOutput/report.html:159-175 (synth.Mixture.realistic)"}
         del rk16, rk48
 
+    # ---- the same path against REPEAT-RICH libraries (synth.Profile.human_repeats: mRNA isoform families, tRNA-like families,
+    # low-complexity stretches): an extra line, never `value`.  The default profile draws `other` and `mrna` as i.i.d. bases --
+    # no repeated k-mers, the best case for direct-addressed slot tables.
+    if solo and args.repeats_reads > 0 and args.profile == "human":
+        rlibs, _ = synth.make_libraries(synth.Profile.human_repeats(), synth.BASE_SEED)
+        rctx = capi.Context(None, 1, local)
+        for i, nm in enumerate(synth.LIB_NAMES):
+            rctx.load_library(i, rlibs[nm].names, rlibs[nm].text, rlibs[nm].offs)
+        rk16, rn16, rk48, rn48, _, _, _ = gen_keys(torch, synth, capi, rctx, rlibs, 0, args.repeats_reads, args.chunk, mix, W, rank,
+                                                   label="reads (repeat-rich libraries)")
+        kw = dict(c=rctx, a=rk16, na=rn16, b=rk48, nb=rn48)
+        step(**kw); step(**kw)
+        nst = max(3, args.steps // 2)
+        rctx.set_kernel_timing(False)
+        fence(); t0 = time.perf_counter()
+        for _ in range(nst):
+            step(**kw)
+        fence(); el = time.perf_counter() - t0
+        rctx.set_kernel_timing(True)
+        kts = []
+        for _ in range(nst):
+            step(**kw)
+            kts.append(rctx.kernel_times())
+        rs = [rctx.round_stats(r + 1) for r in range(5)]
+        _, _, rnd_, _, amb_ = rctx.export_uniques(with_seqs=False)
+        uid_, _, cnt_ = rctx.export_counts()
+        per = np.zeros(len(rnd_), dtype=np.int64); np.add.at(per, uid_.astype(np.int64), cnt_.astype(np.int64))
+        ann = rnd_ > 0
+        out["repeats"] = {"reads": int(args.repeats_reads), "uniques": int(rctx.n_unique()), "ms_per_step": 1e3 * el / nst,
+                          "reads_per_s": args.repeats_reads * nst / el,
+                          "lib_nt": {nm: int(len(rlibs[nm].text)) for nm in synth.LIB_NAMES},
+                          "kernels_ms": {k: round(float(np.mean([kt[k][0] for kt in kts if k in kt])), 4) for k in kts[-1] if k != "pack"},
+                          "round_uniques": [int(x[0]) for x in rs], "round_aligned": [int(x[1]) for x in rs],
+                          "handed_to_generic_kernel": [int(rctx.round_handed_on(r + 1)) for r in range(5)],
+                          "h1_dependent": {"uniques_annotated": int(ann.sum()), "uniques_ambiguous": int((ann & (amb_ > 0)).sum()),
+                                           "reads_annotated": int(per[ann].sum()), "reads_ambiguous": int(per[ann & (amb_ > 0)].sum())},
+                          "note": "synth.Profile.human_repeats: mrna = isoform families (2-6 transcripts per gene sharing >= 70 % of its exons), "
+                                  "other = 60 % tRNA-like families of 10-50 members differing by 1-3 nt + low-complexity stretches; same read "
+                                  "mixture as the headline; handed_to_generic_kernel = uniques per round whose bucket lists the slot-table "
+                                  "kernel refused (> 4096 entries) or could not queue"}
+        rctx.close()
+        del rk16, rk48, rlibs
+
     # ---- end-to-end legs (reported separately, never `value`)
     if solo and e2e_parts:
         import tempfile
@@ -423,6 +467,33 @@ def main():
                     best = cur
             assert nr == ne
             out["e2e"] = best
+            # the same file gzip'd (the reference takes fastq or fastq.gz, miRge.pl:1092): one file = one serial inflate stream;
+            # eight such files as a batch = eight host threads inflating ahead of the device (mirge_collapse_fastq_batch)
+            import zlib
+            raw = open(path, "rb").read()
+            co = zlib.compressobj(1, zlib.DEFLATED, 31)
+            gz = co.compress(raw) + co.flush()
+            del raw
+            gpaths = [os.path.join(tmpd, "g%d.fastq.gz" % i) for i in range(8)]
+            for gp in gpaths:
+                with open(gp, "wb") as f:
+                    f.write(gz)
+            ctx.reset(1)
+            t0 = time.perf_counter(); nr1 = ctx.collapse_fastq(gpaths[0], 0); t_one = time.perf_counter() - t0
+            ctx.reset(8)
+            t0 = time.perf_counter(); totb, _, _ = ctx.collapse_fastq_batch(gpaths, list(range(8))); t_b = time.perf_counter() - t0
+            ctx.annotate(); cvb = ctx.counts()
+            out["e2e_gz"] = {"reads_per_file": int(nr1), "gz_bytes_per_file": len(gz), "fastq_bytes_per_file": int(nbytes),
+                             "single_stream": {"seconds": t_one, "reads_per_s": nr1 / t_one, "gz_GBps": len(gz) / t_one / 1e9},
+                             "batch_of_8": {"seconds": t_b, "reads_per_s": float(totb.sum()) / t_b, "gz_GBps": 8 * len(gz) / t_b / 1e9,
+                                            "speedup_over_single_stream": (float(totb.sum()) / t_b) / (nr1 / t_one),
+                                            "samples_identical": bool(all(int(cvb["tuniq"][i]) == int(cvb["tuniq"][0]) for i in range(8)))},
+                             "host_cpus": os.cpu_count(),
+                             "note": "zlib level 1 files in the page cache -> HBM -> collapse; single = mirge_collapse_fastq (one inflater thread "
+                                     "feeding the pinned ring), batch = mirge_collapse_fastq_batch (one inflater thread per file, up to 16, "
+                                     "files collapsed in sample order as they complete)"}
+            del gz
+            ctx.reset(1)
             # the same from RAW reads: 50-nt reads with the 3' adapter still on, trimming on the device
             nbytes = synth.write_raw_fastq_fast(path, es[:ne], el[:ne], synth.BASE_SEED + 77)
             best = None

@@ -173,6 +173,10 @@ int32_t     mirge_collapse_keys16_noalloc(mirge_ctx*, const void* d_keys16, uint
 int32_t     mirge_annotate(mirge_ctx*);
 /* annotStats of miRge.pl:352-354, 410-413; round is 1-based. */
 int32_t     mirge_round_stats(const mirge_ctx*, int32_t round, uint64_t* processed, uint64_t* aligned, double* seconds);
+/* How many uniques of the round the slot-table kernel could not decide itself and handed to the generic matcher (reads
+ * shorter than any table's key, buckets of more than 4096 entries -- repeats --, a full queue).  A diagnostic of this
+ * implementation; no counterpart in the reference. */
+int32_t     mirge_round_handed_on(const mirge_ctx*, int32_t round, uint64_t* n);
 
 /* ---- count vectors (replaces summarize, miRge.pl:453-494) ----------------
  * quant, iscan: M x S row-major (M = mirge_lib_size(MIRGE_LIB_MIRNA), row =

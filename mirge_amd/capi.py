@@ -30,7 +30,7 @@ EXPORTS = [
     "mirge_verb_export_size", "mirge_verb_export", "mirge_verb_clear", "mirge_verb_import",
     "mirge_n_counts", "mirge_export_counts", "mirge_last_timing", "mirge_kernel_times", "mirge_set_kernel_timing", "mirge_write_tables",
     "mirge_collapse_keys16_noalloc",
-    "mirge_collapse_fastq_batch", "mirge_group_open", "mirge_group_open_ex", "mirge_group_close", "mirge_group_last_error", "mirge_group_size",
+    "mirge_collapse_fastq_batch", "mirge_round_handed_on", "mirge_group_open", "mirge_group_open_ex", "mirge_group_close", "mirge_group_last_error", "mirge_group_size",
     "mirge_group_ctx", "mirge_group_reset", "mirge_group_load_library_mem", "mirge_group_collapse_seqs", "mirge_group_collapse_fastq_batch",
     "mirge_group_annotate", "mirge_group_counts", "mirge_group_round_stats", "mirge_group_n_unique", "mirge_group_write_tables", "mirge_group_timing",
 ]
@@ -95,6 +95,7 @@ def load():
     L.mirge_collapse_keys16_noalloc.argtypes = [vp, vp, u64, vp, vp, C.POINTER(u64)]
     L.mirge_annotate.argtypes = [vp]
     L.mirge_round_stats.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
+    L.mirge_round_handed_on.argtypes = [vp, i32, C.POINTER(u64)]
     L.mirge_counts.argtypes = [vp] + [C.POINTER(C.POINTER(u64))] * 5
     L.mirge_counts_flat_len.restype = u64; L.mirge_counts_flat_len.argtypes = [vp]
     L.mirge_counts_flat_get.argtypes = [vp, vp]
@@ -312,6 +313,11 @@ class Context:
         p = C.c_uint64(); a = C.c_uint64(); s = C.c_double()
         self._chk(self.L.mirge_round_stats(self.h, rnd, C.byref(p), C.byref(a), C.byref(s)))
         return p.value, a.value, s.value
+
+    def round_handed_on(self, rnd):
+        n = C.c_uint64()
+        self._chk(self.L.mirge_round_handed_on(self.h, rnd, C.byref(n)))
+        return n.value
 
     def counts(self):
         ptrs = [C.POINTER(C.c_uint64)() for _ in range(5)]

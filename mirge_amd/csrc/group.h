@@ -95,7 +95,7 @@ int load_file_bytes(const char* path, std::vector<uint8_t>& out, std::string& er
 
 // Files idx[0..m) of a batch -> context c, in that order: up to `nthr` host threads read / inflate files AHEAD (a gzip
 // stream inflates serially, but different files do not wait for each other) while this thread uploads and collapses the
-// ones that are ready.  At most `nthr + 2` files are held in host memory at once.
+// ones that are ready.  At most `nthr + 2` files are held (in host memory while they inflate, then in HBM) at once.
 int collapse_files(mirge_ctx* c, const std::vector<int>& idx, const char* const* paths, const int32_t* samples, const char* adapter,
                    int32_t trim5, int32_t trim3, uint64_t* total_reads, uint64_t* trimmed_reads, int32_t* phred, int nthr) {
     const size_t m = idx.size();
@@ -104,6 +104,7 @@ int collapse_files(mirge_ctx* c, const std::vector<int>& idx, const char* const*
     if (adapter) { int rc = make_trim_plan(c, adapter, trim5, trim3, tp0); if (rc) return rc; }
     nthr = (int)std::max<size_t>(1, std::min<size_t>((size_t)nthr, m));
     std::vector<std::vector<uint8_t>> bufs(m);
+    std::vector<void*> dbuf(m, nullptr); std::vector<uint64_t> dsize(m, 0); std::vector<uint8_t> dlast(m, (uint8_t)'\n');      // the files in HBM
     std::vector<int> state(m, 0);                                  // 0 = not loaded, 1 = ready, -1 = failed
     std::vector<std::string> errs(m);
     std::mutex mu; std::condition_variable cv;
@@ -115,7 +116,18 @@ int collapse_files(mirge_ctx* c, const std::vector<int>& idx, const char* const*
             if (i >= m) return;
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || i < consumed + (size_t)nthr + 2; }); if (stop) return; }
             std::string e;
-            const int rc = load_file_bytes(paths[idx[i]], bufs[i], e);
+            int rc = load_file_bytes(paths[idx[i]], bufs[i], e);
+            if (!rc) {
+                // the worker uploads its file itself (a buffer of its own in HBM): the collapsing thread is left with the
+                // kernels alone, and the uploads of different files overlap the inflating of others
+                const uint64_t size = bufs[i].size();
+                hipError_t he = hipSetDevice(c->device);
+                if (he == hipSuccess) he = hipMalloc(&dbuf[i], size + 256);
+                if (he == hipSuccess && size) he = hipMemcpy(dbuf[i], bufs[i].data(), size, hipMemcpyHostToDevice);
+                if (he != hipSuccess) { rc = MIRGE_E_HIP; e = std::string("FASTQ upload: ") + hipGetErrorString(he); }
+                dsize[i] = size; dlast[i] = size ? bufs[i][size - 1] : (uint8_t)'\n';
+                std::vector<uint8_t>().swap(bufs[i]);
+            }
             { std::lock_guard<std::mutex> lk(mu); state[i] = rc ? -1 : 1; errs[i] = e; }
             cv.notify_all();
         }
@@ -123,37 +135,35 @@ int collapse_files(mirge_ctx* c, const std::vector<int>& idx, const char* const*
     std::vector<std::thread> thr;
     for (int t = 0; t < nthr; ++t) thr.emplace_back(worker);
     int rc = MIRGE_OK;
+    if (hipSetDevice(c->device) != hipSuccess) rc = fail(c, MIRGE_E_HIP, "hipSetDevice failed");
     for (size_t i = 0; i < m && rc == MIRGE_OK; ++i) {
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return state[i] != 0; }); }
         if (state[i] < 0) { rc = fail(c, MIRGE_E_IO, errs[i]); break; }
         const int j = idx[i];
-        std::vector<uint8_t>& b = bufs[i];
-        const uint64_t size = b.size();
-        hipError_t he = hipSetDevice(c->device);
-        if (he == hipSuccess) he = c->fq_raw.ensure(size + 256, false, 0, c->st);
-        if (he == hipSuccess && size) he = hipMemcpyAsync(c->fq_raw.p, b.data(), size, hipMemcpyHostToDevice, c->st);
-        if (he == hipSuccess) he = hipStreamSynchronize(c->st);
-        if (he != hipSuccess) { rc = fail(c, MIRGE_E_HIP, std::string("FASTQ upload: ") + hipGetErrorString(he)); break; }
-        const uint8_t last = size ? b[size - 1] : (uint8_t)'\n';
-        std::vector<uint8_t>().swap(b);
-        { std::lock_guard<std::mutex> lk(mu); consumed = i + 1; }
-        cv.notify_all();
+        const uint64_t size = dsize[i];
+        const uint8_t last = dlast[i];
+        const uint8_t* d = (const uint8_t*)dbuf[i];
         uint64_t n = 0;
         if (adapter) {
             TrimPlan tp = tp0;
-            rc = collapse_fastq_dev(c, c->fq_raw.as<uint8_t>(), size, last, samples[j], &n, &tp);
+            rc = collapse_fastq_dev(c, d, size, last, samples[j], &n, &tp);
             if (trimmed_reads) trimmed_reads[j] = tp.kept;
             if (phred) phred[j] = tp.phred_reported;
         } else {
-            rc = collapse_fastq_dev(c, c->fq_raw.as<uint8_t>(), size, last, samples[j], &n);
+            rc = collapse_fastq_dev(c, d, size, last, samples[j], &n);
             if (trimmed_reads) trimmed_reads[j] = n;
             if (phred) phred[j] = 33;
         }
         if (total_reads) total_reads[j] = n;
+        (void)hipFree(dbuf[i]); dbuf[i] = nullptr;
+        { std::lock_guard<std::mutex> lk(mu); consumed = i + 1; }
+        cv.notify_all();
     }
     { std::lock_guard<std::mutex> lk(mu); stop = true; }
     cv.notify_all();
     for (auto& t : thr) t.join();
+    (void)hipSetDevice(c->device);
+    for (auto& p : dbuf) if (p) (void)hipFree(p);
     return rc;
 }
 

@@ -1993,7 +1993,16 @@ k_match_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
 constexpr int PB = 256;                          // threads per block
 // queued chunks per block: rounds of two-mismatch schemes (NS = 3: 6 lookups of 8- or 6-nt specificity) fill them,
 // the others hardly use them
-template <int NS> struct ProbeQ { static constexpr int Q4 = NS >= 3 ? 768 : 320, Q64 = NS >= 3 ? 256 : 32; };
+// (one size for every instantiation: with 320 / 32 the rounds without two-mismatch schemes overflowed on libraries with
+// repeated k-mers -- tRNA-like families put 10-50 entries behind most lookups of their reads, > 16 such reads per block
+// filled the 32 long chunks, and 2.7 % of the reads went to the generic kernel, which then took 3 ms: bench.py `repeats`)
+#ifndef MG_PQ4
+#define MG_PQ4 768
+#endif
+#ifndef MG_PQ64
+#define MG_PQ64 256
+#endif
+template <int NS> struct ProbeQ { static constexpr int Q4 = MG_PQ4, Q64 = MG_PQ64; };
 #ifndef MG_PROBE_WAVES
 #define MG_PROBE_WAVES 7                        // the scheme-carrying instantiations: 72 registers and 8-12 B of scratch (6 waves: none; 8: round 3 0.99 ms)
 #endif

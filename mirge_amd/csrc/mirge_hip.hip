@@ -219,6 +219,8 @@ struct mirge_ctx {
     // results
     bool annotated = false, counts_valid = false, host_valid = false;
     uint64_t stats[MIRGE_MAX_ROUNDS][2] = {};
+    uint64_t handed_on[MIRGE_MAX_ROUNDS] = {};      // per round: uniques the probe / LDS kernel handed to the generic kernel (both key classes)
+    unsigned long long* h_fb = nullptr;             // pinned: the fb list lengths of the last cascade
     double round_ms[MIRGE_MAX_ROUNDS] = {};
     std::vector<uint64_t> h_quant, h_iscan, h_cat, h_len, h_tu;
     // host copies for per-unique export
@@ -1493,7 +1495,10 @@ int annotate(mirge_ctx* c) {
     { int rj = join_st2(c); if (rj) return rj; }
     if (c->timing) HIPCHK(c, hipEventRecord(e2, c->st));
     HIPCHK(c, hipMemcpyAsync(c->h_state, c->state.p, w_out * 8, hipMemcpyDeviceToHost, c->st));
+    if (!c->h_fb) HIPCHK(c, hipHostMalloc((void**)&c->h_fb, 2 * (2 * MIRGE_MAX_ROUNDS + 1) * 8));
+    HIPCHK(c, hipMemcpyAsync(c->h_fb, c->cls[0].fb_n, 2 * w_fb * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    for (int r = 0; r < MIRGE_MAX_ROUNDS; ++r) c->handed_on[r] = c->h_fb[r] + c->h_fb[w_fb + r];
     if (c->cls[0].pending || c->cls[1].pending) {
         // a fused call: the collapse was queued in front of all this and is settled only now
         bool reran = false;
@@ -1698,6 +1703,7 @@ void mirge_close(mirge_ctx* c) {
     for (auto& k : c->kt) { if (k.a) (void)hipEventDestroy(k.a); if (k.b) (void)hipEventDestroy(k.b); }
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->h_fb) (void)hipHostFree(c->h_fb);
     for (auto& e : c->ev_t) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_c) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1997,6 +2003,12 @@ int32_t mirge_round_stats(const mirge_ctx* c, int32_t round, uint64_t* processed
     if (processed) *processed = c->stats[round - 1][0];
     if (aligned) *aligned = c->stats[round - 1][1];
     if (seconds) *seconds = c->round_ms[round - 1] * 1e-3;
+    return MIRGE_OK;
+}
+
+int32_t mirge_round_handed_on(const mirge_ctx* c, int32_t round, uint64_t* n) {
+    if (!c || round < 1 || round > c->n_rounds || !c->annotated || !n) return MIRGE_E_ARG;
+    *n = c->handed_on[round - 1];
     return MIRGE_OK;
 }
 

@@ -59,10 +59,24 @@ class Profile:
     mrna_median: float = 2500.0
     mrna_cap: int = 20000
     prefix: str = "hsa"
+    # repeat-rich libraries: `mrna` as isoform families (each gene 2-6 transcripts sharing >= 70 % of its exons), `other`
+    # with tRNA-like families (10-50 members differing by 1-3 nt) and a few low-complexity stretches.  The default
+    # profile draws both libraries as i.i.d. uniform bases: no k-mer repeats, the best case for
+    # direct-addressed slot tables.
+    repeats: bool = False
 
     @staticmethod
     def human() -> "Profile":
         return Profile()
+
+    @staticmethod
+    def human_repeats() -> "Profile":
+        return Profile(repeats=True)
+
+    @staticmethod
+    def small_repeats() -> "Profile":
+        return Profile(n_mirna=300, n_snp=10, n_family=6, n_hairpin=200, n_other=900, other_median=120.0,
+                       n_mrna=300, mrna_median=1500.0, mrna_cap=8000, repeats=True)
 
     @staticmethod
     def mouse() -> "Profile":
@@ -148,8 +162,57 @@ def make_libraries(profile: Profile, seed: int = BASE_SEED):
         text = ACGT[rng.integers(0, 4, size=int(offs[-1]))]
         return Library(["%s_%06d" % (tag, i) for i in range(n)], text, offs)
 
-    other = lognormal_lib(P.n_other, P.other_median, 5000, 50, "ncRNA")
-    mrna = lognormal_lib(P.n_mrna, P.mrna_median, P.mrna_cap, 200, "NM")
+    def family_lib(n, median, tag):
+        """~60 % of the entries in families of 10-50 members that differ from their founder by 1-3 substitutions (tRNA-like:
+        every k-mer of a founder occurs 10-50 times), ~1 % of all entries with a low-complexity stretch (a homopolymer or
+        a dinucleotide repeat of 30-60 nt: one k-mer hundreds of times), the rest unrelated."""
+        seqs_ = []
+        while len(seqs_) < int(0.6 * n):
+            founder = _rand_seq(rng, int(np.clip(np.exp(rng.normal(np.log(median * 0.6), 0.2)), 60, 200)))
+            for _ in range(int(rng.integers(10, 51))):
+                seqs_.append(_mutate(rng, founder, int(rng.integers(1, 4))))
+        seqs_ = seqs_[:int(0.6 * n)]
+        while len(seqs_) < n:
+            seqs_.append(_rand_seq(rng, int(np.clip(np.exp(rng.normal(np.log(median), 0.6)), 50, 5000))))
+        for i in rng.choice(n, size=max(1, n // 100), replace=False):
+            L = int(rng.integers(30, 61))
+            unit = [b"A", b"T", b"CA", b"GT", b"AT"][int(rng.integers(0, 5))]
+            rep = np.frombuffer((unit * L)[:L], dtype=np.uint8)
+            if len(seqs_[i]) > L + 10:
+                p = int(rng.integers(0, len(seqs_[i]) - L))
+                seqs_[i] = seqs_[i].copy(); seqs_[i][p:p + L] = rep
+        order_ = rng.permutation(n)
+        lens = np.array([len(seqs_[i]) for i in order_], dtype=np.int64)
+        offs = np.zeros(n + 1, dtype=np.int64); np.cumsum(lens, out=offs[1:])
+        return Library(["%s_%06d" % (tag, i) for i in range(n)], np.concatenate([seqs_[i] for i in order_]), offs)
+
+    def isoform_lib(n, median, cap, tag):
+        """Genes of 4-16 exons; 2-6 transcripts per gene, each keeping >= 70 % of the gene's exons (the first and last
+        always): most k-mers of the library occur once per isoform of their gene."""
+        parts, lens = [], []
+        while len(lens) < n:
+            target = float(np.clip(np.exp(rng.normal(np.log(median), 0.6)), 200, cap))
+            nex = int(rng.integers(4, 17))
+            cut = np.sort(rng.random(nex - 1)); w = np.diff(np.concatenate([[0.0], cut, [1.0]]))
+            exons = [_rand_seq(rng, max(30, int(target * 1.15 * x))) for x in w]
+            for _ in range(int(rng.integers(2, 7))):
+                if len(lens) >= n:
+                    break
+                keep = rng.random(nex) < 0.85
+                keep[0] = keep[-1] = True
+                while keep.sum() < int(np.ceil(0.7 * nex)):
+                    keep[int(rng.integers(0, nex))] = True
+                t = np.concatenate([e for e, k in zip(exons, keep) if k])[:cap]
+                parts.append(t); lens.append(len(t))
+        offs = np.zeros(n + 1, dtype=np.int64); np.cumsum(np.array(lens, dtype=np.int64), out=offs[1:])
+        return Library(["%s_%06d" % (tag, i) for i in range(n)], np.concatenate(parts), offs)
+
+    if P.repeats:
+        other = family_lib(P.n_other, P.other_median, "ncRNA")
+        mrna = isoform_lib(P.n_mrna, P.mrna_median, P.mrna_cap, "NM")
+    else:
+        other = lognormal_lib(P.n_other, P.other_median, 5000, 50, "ncRNA")
+        mrna = lognormal_lib(P.n_mrna, P.mrna_median, P.mrna_cap, 200, "NM")
     return {"mirna": mirna, "hairpin": hairpin, "other": other, "mrna": mrna}, merges
 
 

@@ -104,3 +104,35 @@ def test_cascades_that_mix_probe_and_generic_rounds(oracle, monkeypatch, seed, l
     for k in ("quant", "iscan", "cat", "tuniq", "lenhist"):
         assert np.array_equal(cv[k], res[k]), (k, rounds)
     assert stats == [(int(a), int(b)) for a, b in res["stats"]][:len(rounds)], rounds
+
+
+@pytest.mark.parametrize("kb,lds", [(4, "0"), (7, "0"), (11, "0"), (7, "1")])
+def test_repeat_rich_libraries(oracle, monkeypatch, kb, lds):
+    """Libraries with repeated k-mers (synth.Profile.small_repeats: tRNA-like families of 10-50 near-identical members,
+    low-complexity stretches, mRNA isoforms sharing exons) instead of i.i.d. bases: bucket lists of tens to thousands of
+    entries, most hits with several equally good references.  kb = 4 puts > 4096 entries into most buckets of the larger
+    libraries, so those reads are handed to the generic kernel; every assignment and every ambiguity flag against the
+    oracle."""
+    monkeypatch.setenv("MIRGE_LDS", lds)
+    monkeypatch.setenv("MIRGE_SLOTS_MIN_KB", "4")
+    monkeypatch.setenv("MIRGE_KB", str(kb))
+    libs, _ = synth.make_libraries(synth.Profile.small_repeats(), 900 + kb)
+    samples = [synth.make_reads(libs, 30000, 910 + kb)]
+    S = 1
+    with capi.Context(None, S, 0) as ctx:
+        util.load_libs_into(ctx, libs)
+        ctx.collapse_seqs(samples[0][0], 0, samples[0][1])
+        ctx.annotate()
+        got = util.gpu_result_dict(ctx)
+        cv = ctx.counts()
+        stats = [ctx.round_stats(r + 1)[:2] for r in range(5)]
+        handed = [ctx.round_handed_on(r + 1) for r in range(5)]
+    res = oracle.run_path(util.oracle_libs(libs, oracle), samples, use_index=True, nthreads=8, maxlen=capi.MAX_READ_LEN)
+    assert got == util.oracle_result_dict(res)
+    for k in ("quant", "iscan", "cat", "tuniq", "lenhist"):
+        assert np.array_equal(cv[k], res[k]), k
+    assert stats == [(int(a), int(b)) for a, b in res["stats"]]
+    amb = sum(1 for v in got.values() if v[0] > 0 and v[2])
+    assert amb > 1000, amb                                           # ties are the rule here, not the exception
+    if kb == 4:
+        assert sum(handed) > 1000, handed                            # over-long buckets: the hand-over to the generic kernel ran

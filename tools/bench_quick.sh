@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick A/B on the GPU box: bench_quick.sh "<ENV=VAL ...>" ...   -> one line per configuration (BQ_ARGS: extra bench.py arguments)
 for cfg in "$@"; do
-  env $cfg timeout -k 10 200 python -u bench.py --steps 3 --warmup 1 --cpu-sample 0 --e2e-reads 0 --realistic-reads 0 --perl-reads 0 $BQ_ARGS > gpurun_out/bq.json 2>/dev/null
+  env $cfg timeout -k 10 200 python -u bench.py --steps 3 --warmup 1 --cpu-sample 0 --e2e-reads 0 --realistic-reads 0 --perl-reads 0 --repeats-reads 0 $BQ_ARGS > gpurun_out/bq.json 2>/dev/null
   python - "$cfg" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/bq.json"))

@@ -5,7 +5,7 @@ set -e
 tag=${1:-run}; root=$PWD; out=$root/gpurun_out/prof_$tag; mkdir -p $out
 export TMPDIR=/tmp
 cd $root
-B="python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 --e2e-reads 0 --realistic-reads 0 --perl-reads 0"   # every launch in these passes is a full-size (20M-read) one
+B="python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 --e2e-reads 0 --realistic-reads 0 --perl-reads 0 --repeats-reads 0"   # every launch in these passes is a full-size (20M-read) one
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $B > $out/bench_under_rocprof.json
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- $B > /dev/null
 timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- $B > /dev/null
