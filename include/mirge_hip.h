@@ -155,8 +155,9 @@ int32_t     mirge_collapse_annotate_packed_dev(mirge_ctx*, const void* d_keys16,
  * MIRGE_E_FORMAT names the first malformed key. */
 int32_t     mirge_validate_keys_dev(mirge_ctx*, const void* d_keys16, uint64_t n16, const void* d_keys48, uint64_t n48);
 
-/* NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate device memory -- code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc: the collapse step of mirge_collapse_packed_dev for one stream
+/* NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate device memory -- tight serving loops, harnesses
+ * that forbid hipMalloc (NOT for use under HIP graph capture: the call works on the library's own stream and ends with
+ * a device-to-host copy and a stream synchronise): the collapse step of mirge_collapse_packed_dev for one stream
  * of n 16-byte keys, with every workspace of its kernels (slot table, duplicate counters, ranks) in a fixed array
  * inside the library (about 20 MB, held by every GPU the library runs on until the process ends) and the results in the
  * caller's buffers: d_ukeys receives the distinct keys (room for n x 16 bytes), d_counts[j] the number of input keys

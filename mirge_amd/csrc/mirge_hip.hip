@@ -821,6 +821,7 @@ int collapse_host(mirge_ctx* c, const char* seqs, const uint64_t* offs, uint64_t
     HIPCHK(c, hipMemsetAsync(c->ctr.p, 0, 128, c->st));
     HIPCHK(c, c->stage16.ensure(std::max<uint64_t>(n, 1) * 16, false, 0, c->st));
     std::vector<uint8_t> mat, lens, kind;
+    std::vector<uint64_t> verb_later;                            // reads no key holds, by index
     uint64_t n16 = 0, n48 = 0;
     for (uint64_t b = 0; b < n; b += CH) {
         const uint64_t m = std::min(CH, n - b);
@@ -863,9 +864,14 @@ int collapse_host(mirge_ctx* c, const char* seqs, const uint64_t* offs, uint64_t
         }
         if (rows < m)
             for (uint64_t i = 0; i < m; ++i)
-                if (kind[(size_t)i] == 1) c->vb.add(seqs + offs[b + i], (size_t)(offs[b + i + 1] - offs[b + i]), sample, c->S, 1);
+                if (kind[(size_t)i] == 1) verb_later.push_back(b + i);
     }
-    return collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
+    // the verbatim reads join their table only once nothing can fail any more: a refused read in a later chunk, or a
+    // failed collapse, leaves the context as it was before the call
+    int rc = collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
+    if (rc) return rc;
+    for (uint64_t i : verb_later) c->vb.add(seqs + offs[i], (size_t)(offs[i + 1] - offs[i]), sample, c->S, 1);
+    return MIRGE_OK;
 }
 
 
@@ -1885,7 +1891,7 @@ int32_t mirge_verb_import(mirge_ctx* c, const void* blob, uint64_t nbytes, int32
         uint32_t h[3];
         if (end - p < 12) return fail(c, MIRGE_E_FORMAT, "truncated verbatim-read blob");
         memcpy(h, p, 12); p += 12;
-        if ((uint64_t)(end - p) < h[0] || h[0] > MIRGE_MAX_READ_LEN || (int)h[1] >= c->S) return fail(c, MIRGE_E_FORMAT, "corrupt verbatim-read blob");
+        if ((uint64_t)(end - p) < h[0] || h[0] > MIRGE_MAX_READ_LEN || h[1] >= (uint32_t)c->S || h[2] == 0) return fail(c, MIRGE_E_FORMAT, "corrupt verbatim-read blob");
         uint64_t f = 1469598103934665603ull;
         for (uint32_t i = 0; i < h[0]; ++i) { f ^= p[i]; f *= 1099511628211ull; }
         if ((int32_t)((f >> 17) % (uint64_t)world) == rank) c->vb.add((const char*)p, h[0], (int)h[1], c->S, h[2]);

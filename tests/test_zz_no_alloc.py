@@ -32,7 +32,10 @@ def test_no_alloc_collapse_equals_collapse_packed_dev():
             k16 = _keys16(ctx, torch, n, synth.BASE_SEED + seed)
             m = k16.shape[0]
             uk.fill_(-1); uc.fill_(-1)
+            torch.cuda.synchronize()
+            free_before = torch.cuda.mem_get_info()[0]          # hipMemGetInfo: what the device has left
             U = ctx.collapse_keys16_noalloc(k16.data_ptr(), m, uk.data_ptr(), uc.data_ptr())
+            assert torch.cuda.mem_get_info()[0] == free_before, "the call took (or gave back) device memory"
             got = _table_of(uk[:U].cpu().numpy().view(np.uint64), uc[:U].cpu().numpy().view(np.uint32))
             assert len(got) == U                                # distinct keys came out distinct
             ctx.reset()
@@ -61,3 +64,29 @@ def test_no_alloc_collapse_equals_collapse_packed_dev():
             ctx.collapse_keys16_noalloc(k16.data_ptr(), big, uk.data_ptr(), uc.data_ptr())
         assert ei.value.code == capi.MIRGE_E_LIMIT
         assert ctx.collapse_keys16_noalloc(k16.data_ptr(), 0, uk.data_ptr(), uc.data_ptr()) == 0
+
+
+def test_no_alloc_collapse_at_its_maximum_size():
+    """n = MIRGE_NOALLOC_MAX_KEYS, nearly all keys distinct: the slot table at its largest, the per-key counters and ranks
+    filled to their last element; against mirge_collapse_packed_dev, and without a byte of device memory taken."""
+    import torch
+    n = capi.NOALLOC_MAX_KEYS
+    rng = np.random.default_rng(77)
+    w0 = rng.integers(0, 1 << 62, size=n, dtype=np.int64) & ((1 << 62) - 1)
+    w0[: n // 50] = w0[n // 50: 2 * (n // 50)]                  # 2 % duplicates
+    keys = np.stack([w0, np.full(n, 31 << 56, dtype=np.int64)], axis=1)      # 31-nt reads: all bits of w0 below 2 * 31 are sequence
+    with capi.Context(None, 1, 0) as ctx:
+        k16 = torch.from_numpy(keys).cuda()
+        uk = torch.empty((n, 2), dtype=torch.int64, device="cuda"); uc = torch.empty(n, dtype=torch.int32, device="cuda")
+        empty48 = torch.zeros((1, 6), dtype=torch.int64, device="cuda")
+        ctx.validate_keys_dev(k16.data_ptr(), n, empty48.data_ptr(), 0)
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        U = ctx.collapse_keys16_noalloc(k16.data_ptr(), n, uk.data_ptr(), uc.data_ptr())
+        assert torch.cuda.mem_get_info()[0] == free_before
+        got = _table_of(uk[:U].cpu().numpy().view(np.uint64), uc[:U].cpu().numpy().view(np.uint32))
+        uniq, cnt = np.unique(keys[:, 0].view(np.uint64), return_counts=True)
+        assert U == len(uniq) == len(got)
+        assert got == {(int(a), 31 << 56): int(c) for a, c in zip(uniq.tolist(), cnt.tolist())}
+        ctx.collapse_packed_dev(k16.data_ptr(), n, empty48.data_ptr(), 0, 0)
+        assert ctx.n_unique() == U
