@@ -2641,13 +2641,16 @@ k_counts(const uint32_t* __restrict__ coo_g, const uint32_t* __restrict__ coo_c,
          const uint64_t* __restrict__ ukeys, const uint8_t* __restrict__ ann_round, const int32_t* __restrict__ ann_ref,
          int M, uint32_t round_libs, uint32_t iscan_rounds, unsigned long long* quant, unsigned long long* iscan,
          unsigned long long* cat, unsigned long long* lenhist, unsigned long long* tuniq,
-         const unsigned long long* __restrict__ n_dev) {
+         const unsigned long long* __restrict__ n_dev, bool lds_cols) {
+    // lds_cols: the launch brought 2 * M words of dynamic LDS for the quant / iscan columns (the host leaves them out
+    // for a handful of entries: a 43 KB block finds no room on CUs that the cascade's blocks fill, and the 48-byte
+    // class's 40 K entries waited 0.45 ms for one)
     extern __shared__ unsigned long long s_dyn[];
     if (n_dev) { const uint32_t nd = (uint32_t)(*n_dev & 0xFFFFFFFFull); n = nd < n ? nd : n; }      // the entry count is still on the device (low half of the collapse's rank counter); n was an upper bound
     __shared__ unsigned long long s_cat[5];
     __shared__ unsigned long long s_len[128];
     __shared__ unsigned long long s_tu;
-    const bool ldsm = M <= CNT_LDS_M;
+    const bool ldsm = M <= CNT_LDS_M && M > 0 && (int)n >= 0 && lds_cols;
     unsigned long long* s_q = s_dyn;
     unsigned long long* s_i = s_dyn + (ldsm ? M : 0);
     for (int j = threadIdx.x; j < 128; j += blockDim.x) s_len[j] = 0;

@@ -1344,30 +1344,33 @@ int annotate_class(mirge_ctx* c, Class& C, int r, const mirge_round& R) {
     return MIRGE_OK;
 }
 
+// fewer entries than this: global atomics, no LDS columns (kernels.h: k_counts).  MIRGE_CNT_LDS_MIN: tests put the LDS form on small inputs
+inline uint64_t cnt_lds_min() { if (const char* e = getenv("MIRGE_CNT_LDS_MIN")) return strtoull(e, nullptr, 10); return 1u << 18; }
 template <int KW>
 int counts_class(mirge_ctx* c, Class& C, int M) {
+    const uint64_t CNT_LDS_MIN_ENTRIES = cnt_lds_min();
     uint32_t round_libs = 0;
     for (int r = 0; r < c->n_rounds; ++r) round_libs |= (uint32_t)(c->rounds[r].lib & 3) << (2 * r);
     const uint32_t iscan_rounds = c->rounds[0].lib == MIRGE_LIB_MIRNA ? 1u : 0u;      // miRge.pl:472-475: annot 1 only
     for (auto& sg : C.segs) {
         if (!sg.count) continue;
-        const size_t lds = M <= CNT_LDS_M ? (size_t)2 * M * 8 : 0;
+        const size_t lds = (M <= CNT_LDS_M && sg.count >= CNT_LDS_MIN_ENTRIES) ? (size_t)2 * M * 8 : 0;
         const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (150u << 10) / (lds + 2048)));      // blocks a CU's LDS holds
         uint32_t grid = (uint32_t)std::min<uint64_t>(256 * per_cu, (sg.count + 255) / 256);
         hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(256), lds, C.st, C.coo_g.as<uint32_t>() + sg.start,
                            C.coo_c.as<uint32_t>() + sg.start, (uint32_t)sg.count, sg.sample, c->S, C.ukeys.as<uint64_t>(),
                            C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), M, round_libs, iscan_rounds,
-                           c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu, (const unsigned long long*)nullptr);
+                           c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu, (const unsigned long long*)nullptr, lds != 0);
     }
     if (C.pending && C.pend_n) {
         // the sample of a deferred collapse: its entries follow the settled ones, how many there are the kernel reads itself
-        const size_t lds = M <= CNT_LDS_M ? (size_t)2 * M * 8 : 0;
+        const size_t lds = (M <= CNT_LDS_M && C.pend_n >= CNT_LDS_MIN_ENTRIES) ? (size_t)2 * M * 8 : 0;
         const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (150u << 10) / (lds + 2048)));
         uint32_t grid = (uint32_t)std::min<uint64_t>(256 * per_cu, ((uint64_t)C.pend_n + 255) / 256);
         hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(256), lds, C.st, C.coo_g.as<uint32_t>() + C.coo_n,
                            C.coo_c.as<uint32_t>() + C.coo_n, C.pend_n, C.pend_sample, c->S, C.ukeys.as<uint64_t>(),
                            C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), M, round_libs, iscan_rounds,
-                           c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu, C.ws_ctr.as<unsigned long long>());
+                           c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu, C.ws_ctr.as<unsigned long long>(), lds != 0);
     }
     HIPCHK(c, hipGetLastError());
     return MIRGE_OK;

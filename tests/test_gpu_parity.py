@@ -373,6 +373,15 @@ def test_large_mirna_library_counts_through_global_atomics(oracle):
     _compare_with_oracle(oracle, libs, samples)
 
 
+def test_counts_with_lds_columns_on_a_small_input(oracle, monkeypatch):
+    """The count kernel keeps the quant / iscan columns in LDS only from 2^18 entries up (below that the 2 x M x 8 B of
+    dynamic LDS per block cost more than they save): MIRGE_CNT_LDS_MIN = 0 puts that form on a test-sized input."""
+    monkeypatch.setenv("MIRGE_CNT_LDS_MIN", "0")
+    libs, _ = synth.make_libraries(synth.Profile.small(), 921)
+    samples = [synth.make_reads(libs, 40000, 922 + s) for s in range(3)]
+    _compare_with_oracle(oracle, libs, samples)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_random_cascades_vs_oracle(oracle, seed):
     """Cascades other than miRge's five rounds (the list of rounds is data): random libraries per round,

@@ -8,7 +8,8 @@ summed and divided by <steps> (the timed steps come last), and symbols that make
 mirge_kernel_times (a round = its probe kernel + the generic kernel over what that hands on; the partitioned collapse =
 both split passes) are added up.  rocprofv3 reports both
 counters in KiB; traffic = 2*FETCH + WRITE bytes (MI355X_MICROARCH.md, "HBM [CDNA4]": on gfx950 FETCH_SIZE
-tallies each 128-B request as 64 B; WRITE_SIZE is exact for streaming stores).  Kernel keys follow the
+tallies each 128-B request as 64 B -- tools/calib_fetch.sh measured the same factor for scattered 32-byte loads;
+WRITE_SIZE is exact for streaming stores).  Kernel keys follow the
 names `mirge_kernel_times` reports, so bench.py can look its dominant kernel up.
 """
 import csv
@@ -22,9 +23,9 @@ def key_of(name):
     m = re.search(r"k_match_round<(\d+), (\d+)>", name)
     if m:
         return "match_round%d%s" % (int(m.group(2)) + 1, "" if m.group(1) == "2" else "_48")
-    m = re.search(r"k_(probe|lds)_round<(\d+), (\d+)>", name)
+    m = re.search(r"k_(probe|lds)_round<(\d+), (\d+)(?:, (\d+))?", name)
     if m:
-        return "match_round%d" % (int(m.group(2)) + 1)
+        return "match_round%d%s" % (int(m.group(2)) + 1, "_48" if m.group(4) == "6" else "")
     if "k_part_pass" in name:
         return "collapse_part16"
     if "k_part_fold" in name:
@@ -64,8 +65,9 @@ def main(a):
     json.dump({"unit": "bytes per launch", "reads": reads, "profile": profile, "lib_sha16": sha,
                "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB * 1024), mean of the last "
                        "%d steps of each kernel; kernels = 2*FETCH + WRITE per MI355X_MICROARCH.md (gfx950 FETCH_SIZE "
-                       "counts 64 B per 128-B request); uncalibrated for scattered 16-B accesses; Infinity-Cache hits "
-                       "are counted (fabric-side counters)" % steps,
+                       "counts 64 B per 128-B request); calibrated for scattered loads by tools/calib_fetch.sh "
+                       "(profiles/r03/calib_fetch_size.txt: a random 32-byte load from a table beyond the L2 is reported as "
+                       "64.0 B, x2 = the 128-B line it moves); Infinity-Cache hits are counted (fabric-side counters)" % steps,
                "kernels": {k: int(2 * f.get(k, 0) + w.get(k, 0)) for k in ks},
                "raw_fetch": {k: int(f.get(k, 0)) for k in ks}, "raw_write": {k: int(w.get(k, 0)) for k in ks}},
               open(out, "w"), indent=1, sort_keys=True)
