@@ -384,8 +384,17 @@ k_validate_keys(const uint64_t* __restrict__ keys, uint64_t n, unsigned long lon
 //   k_part_fold : one final partition (<= PT_C2 records) in LDS -> folded -> its uniques appended to the table as
 //                 k_collapse_emit does (one packed atomic per partition).
 // Regions have fixed capacities; a pass that would overrun one raises `overflow` and the host runs the table form.
-#ifndef MG_PT_TILE
-#define MG_PT_TILE 2048
+#ifndef MG_PT_TILE1
+#define MG_PT_TILE1 1024
+#endif
+#ifndef MG_PT_BLOCK1
+#define MG_PT_BLOCK1 512
+#endif
+#ifndef MG_PT_TILE2
+#define MG_PT_TILE2 2048
+#endif
+#ifndef MG_PT_BLOCK2
+#define MG_PT_BLOCK2 1024
 #endif
 #ifndef MG_PT_P2
 #define MG_PT_P2 256
@@ -393,9 +402,18 @@ k_validate_keys(const uint64_t* __restrict__ keys, uint64_t n, unsigned long lon
 #ifndef MG_PT_C2
 #define MG_PT_C2 2048
 #endif
-constexpr int PT_TILE = MG_PT_TILE, PT_BLOCK = 1024;
+#ifndef MG_PT_EXP
+#define MG_PT_EXP 0                              // phase elimination (timing only, results wrong): profiles/r03/collapse_experiments.txt
+#endif
+#ifndef MG_PT_FBLOCK
+#define MG_PT_FBLOCK 1024
+#endif
+// records of a tile / threads of a block, first and second split pass; threads of a fold block.  The passes differ: every
+// tile of the FIRST pass bumps the same P1 cursors, the second pass's tiles spread over P1 x 256 of them (k_part_pass).
+constexpr int PT_TILE1 = MG_PT_TILE1, PT_BLOCK1 = MG_PT_BLOCK1, PT_TILE2 = MG_PT_TILE2, PT_BLOCK2 = MG_PT_BLOCK2, PT_FBLOCK = MG_PT_FBLOCK;
 constexpr int PT_P2 = MG_PT_P2;                  // fan-out of pass 2 (pass 1: 16 .. 512, by input size)
 constexpr int PT_C2 = MG_PT_C2;                  // records a final partition may hold
+constexpr int LL_CSTRIDE = 16;                   // 8-byte words between the two length words of the length-class lists (a line each: atomics on one line are served one after the other)
 constexpr int pt_log2(int x) { return x <= 1 ? 0 : 1 + pt_log2(x / 2); }
 // Buckets by multiply-shift on the top 32 hash bits x, so that pass 1 can have ANY fan-out P1: x * P1 = bucket * 2^32 +
 // rest; pass 1 takes the bucket, pass 2 the top log2(P2) bits of the rest (uniform inside a bucket, and far above the
@@ -404,50 +422,59 @@ MG_HD uint32_t pt_bucket(uint64_t h64, uint32_t p1, int sel) {
     const uint64_t x = (h64 >> 32) * (uint64_t)p1;
     return sel ? (uint32_t)x >> (32 - pt_log2(PT_P2)) : (uint32_t)(x >> 32);
 }
-template <int NB>
+template <int NB, int PT_TILE, int PT_BLOCK>
 __global__ void __launch_bounds__(PT_BLOCK)
 k_part_pass(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ wt_in, const unsigned long long* __restrict__ n_in, uint32_t n_max,
             uint32_t in_stride, uint32_t p1, int sel, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ wt_out, unsigned long long* cursor,
-            uint32_t cap_out, unsigned long long* overflow) {
-    // blockIdx.y = input partition (its records start in_stride records further on; n_in[p] of them, at most n_max),
-    // blockIdx.x = first tile; a block strides over the partition's tiles (the launches give every tile its own block:
-    // the host's part_grid() says why), the next tile's records on their way into registers while this one is worked on
-    // in LDS.  Keys AND counts of a tile are fetched before the first barrier: a count fetched where it is added (inside
-    // the de-duplication loop) put a global load into the middle of the tile's LDS phase -- 0.53 -> 0.47 ms for both passes.
-    // wt_in (nullable) = a count per input record.
+            uint32_t cap_out, unsigned long long* overflow, uint32_t gmul, uint32_t gdiv, uint32_t cs_in, uint32_t cs_out) {
+    // blockIdx.y = input partition (its records start in_stride records further on; n_in[p * cs_in] of them, at most
+    // n_max), blockIdx.x = tile: a block per tile (resident blocks that stride over the tiles with the next tile on its
+    // way into registers were measured slower: blocks that come and go overlap better).  Keys AND counts of a tile are
+    // fetched before the first barrier: a count fetched where it is added (inside the de-duplication loop) put a global
+    // load into the middle of the tile's LDS phase -- 0.53 -> 0.47 ms for both passes.  wt_in (nullable) = a count per
+    // input record.
+    // What bounds a pass (profiles/r03/collapse_experiments.txt, phase elimination at 20M reads, first pass): loads +
+    // LDS fill alone 0.114 ms of 0.223; the stores 0.078; the de-duplication 0.03; the cursor atomics nothing -- a block
+    // holds its LDS while its loads arrive and while its stores drain, and the pass moves 660 MB at 70 % of the
+    // machine's copy rate.  What the atomics DO cost, they cost as a chain:
+    // * cursors cs_out 8-byte words apart (first pass: 512 B, the host's part_cstride()): atomics on one 128-B line are
+    //   served one after the other, and 16 cursors to a line made the first pass 0.269 ms instead of 0.223;
+    // * cursor groups (gmul = G > 1 in the first pass, gdiv = G in the second): every tile of the first pass bumps every
+    //   one of its P1 cursors, ~12 ns each per address, so the pass cannot be shorter than tiles x 12 ns (0.117 ms at
+    //   tiles of 2048 records, 0.234 at 1024, 0.47 at 512 -- measured 0.223 / 0.291 / 0.496).  With G cursors (and
+    //   regions) per bucket, tile t appending to region (bucket, t mod G), the chain is G times shorter and the first
+    //   pass can take SMALLER tiles, more of which fit a CU: 1024 records x 512 threads, four blocks per CU, G = 8:
+    //   0.196 ms.  The second pass takes the G regions of a bucket as G input partitions (blockIdx.y = bucket * G +
+    //   group) that share the bucket's output cursors; its own cursors are P1 x 256, no chain, and it keeps tiles of 2048
+    //   records (0.195 ms; 0.212 at 1024: runs of 4 records per bucket and tile combine worse than runs of 8).
+    constexpr int PT_TSLOTS = 2 * PT_TILE;                      // slots of the tile's LDS table
     __shared__ uint64_t tk[PT_TILE * 2];
-    __shared__ uint32_t towner[2 * PT_TILE];
+    __shared__ uint32_t towner[PT_TSLOTS];
     __shared__ uint32_t tcnt[PT_TILE];
-    __shared__ uint32_t hist[NB], gbase[NB];
+    __shared__ uint32_t hist[NB];
+    uint32_t* gbase = towner;                                   // (dead by the time the bases are written)
+    static_assert(NB <= PT_TSLOTS, "bucket bases lie over the table slots");
     constexpr int PER = PT_TILE / PT_BLOCK, KL = 2 * PER;
-    const uint32_t tid = threadIdx.x, p = blockIdx.y;
-    const uint32_t n = n_in ? (uint32_t)(n_in[p] < n_max ? n_in[p] : n_max) : n_max;
-    uint64_t base = (uint64_t)blockIdx.x * PT_TILE;
+    const uint32_t tid = threadIdx.x, p = blockIdx.y, po = p / gdiv, grp = blockIdx.x % gmul;
+    const uint32_t n = n_in ? (uint32_t)(n_in[(uint64_t)p * cs_in] < n_max ? n_in[(uint64_t)p * cs_in] : n_max) : n_max;
+    const uint64_t base = (uint64_t)blockIdx.x * PT_TILE;
     if (base >= n) return;
-    const uint64_t step = (uint64_t)gridDim.x * PT_TILE;
-    const uint64_t* kbase = keys_in + (uint64_t)p * in_stride * 2;
-    const uint32_t* wbase = wt_in ? wt_in + (uint64_t)p * in_stride : nullptr;
-    uint64_t pk[KL]; uint32_t pw[PER];
-    auto fetch = [&](uint64_t b) {
-        const uint32_t nv = n - b < (uint64_t)PT_TILE ? (uint32_t)(n - b) : (uint32_t)PT_TILE;
-#pragma unroll
-        for (int e = 0; e < KL; ++e) { const uint32_t j = tid + e * PT_BLOCK; pk[e] = j < nv * 2 ? kbase[b * 2 + j] : 0ull; }
-#pragma unroll
-        for (int e = 0; e < PER; ++e) { const uint32_t idx = tid + e * PT_BLOCK; pw[e] = (wbase && idx < nv) ? wbase[b + idx] : 1u; }
-    };
-    fetch(base);
-    for (;;) {
     const uint32_t nvalid = n - base < (uint64_t)PT_TILE ? (uint32_t)(n - base) : (uint32_t)PT_TILE;
+    const uint64_t* kin = keys_in + ((uint64_t)p * in_stride + base) * 2;
+    const uint32_t* win = wt_in ? wt_in + (uint64_t)p * in_stride + base : nullptr;
     uint32_t wcur[PER];
+    {
+        uint64_t pk[KL];
 #pragma unroll
-    for (int e = 0; e < KL; ++e) tk[tid + e * PT_BLOCK] = pk[e];
+        for (int e = 0; e < KL; ++e) { const uint32_t j = tid + e * PT_BLOCK; pk[e] = j < nvalid * 2 ? kin[j] : 0ull; }
 #pragma unroll
-    for (int e = 0; e < PER; ++e) wcur[e] = pw[e];
-    for (uint32_t j = tid; j < 2u * PT_TILE; j += PT_BLOCK) towner[j] = EMPTY;
-    for (uint32_t j = tid; j < (uint32_t)PT_TILE; j += PT_BLOCK) tcnt[j] = 0;
-    if (tid < (uint32_t)NB) hist[tid] = 0;
-    const bool more = base + step < n;
-    if (more) fetch(base + step);
+        for (int e = 0; e < PER; ++e) { const uint32_t idx = tid + e * PT_BLOCK; wcur[e] = (win && idx < nvalid) ? win[idx] : 1u; }
+        for (uint32_t j = tid; j < (uint32_t)PT_TSLOTS; j += PT_BLOCK) towner[j] = EMPTY;
+        for (uint32_t j = tid; j < (uint32_t)PT_TILE; j += PT_BLOCK) tcnt[j] = 0;
+        for (uint32_t b = tid; b < (uint32_t)NB; b += PT_BLOCK) hist[b] = 0;
+#pragma unroll
+        for (int e = 0; e < KL; ++e) tk[tid + e * PT_BLOCK] = pk[e];
+    }
     __syncthreads();
     uint32_t trep[PER]; uint64_t h64[PER];
 #pragma unroll
@@ -457,17 +484,25 @@ k_part_pass(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
         if (idx < nvalid) {
             uint64_t k[2] = {tk[idx * 2], tk[idx * 2 + 1]};
             h64[e] = key_hash64<2>(k);
-            uint32_t h = (uint32_t)h64[e] & (2u * PT_TILE - 1);
+            uint32_t h = (uint32_t)h64[e] & (uint32_t)(PT_TSLOTS - 1);                             // (the buckets take the top 32 hash bits)
+#if MG_PT_EXP == 3
+            trep[e] = idx; tcnt[idx] = wcur[e]; (void)h;
+#else
             for (;;) {
                 const uint32_t o = atomicCAS(&towner[h], EMPTY, idx);
                 if (o == EMPTY) { trep[e] = idx; break; }
                 if (tk[o * 2] == k[0] && tk[o * 2 + 1] == k[1]) { trep[e] = o; break; }
-                h = (h + 1) & (2u * PT_TILE - 1);
+                h = (h + 1) & (uint32_t)(PT_TSLOTS - 1);
             }
             atomicAdd(&tcnt[trep[e]], wcur[e]);
+#endif
         }
     }
     __syncthreads();
+#if MG_PT_EXP == 4
+    if (tk[tid] == 0x1234567ull) keys_out[0] = 1;
+    return;
+#endif
     uint32_t rank[PER], bk[PER];
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
@@ -476,14 +511,18 @@ k_part_pass(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
         if (idx < nvalid && trep[e] == idx) { bk[e] = pt_bucket(h64[e], p1, sel); rank[e] = atomicAdd(&hist[bk[e]], 1u); }
     }
     __syncthreads();
-    if (tid < (uint32_t)NB) {
-        const uint32_t c = hist[tid];
+    for (uint32_t b = tid; b < (uint32_t)NB; b += PT_BLOCK) {
+        const uint32_t c = hist[b];
         unsigned long long at = 0;
         if (c) {
-            at = atomicAdd(&cursor[(uint64_t)p * NB + tid], (unsigned long long)c);
+#if MG_PT_EXP == 2
+            at = ((uint64_t)blockIdx.x * 40) % (cap_out - 100);
+#else
+            at = atomicAdd(&cursor[(((uint64_t)po * NB + b) * gmul + grp) * cs_out], (unsigned long long)c);
             if (at + c > cap_out) *overflow = 1ull;
+#endif
         }
-        gbase[tid] = (uint32_t)(at < cap_out ? at : cap_out);
+        gbase[b] = (uint32_t)(at < cap_out ? at : cap_out);
     }
     __syncthreads();
 #pragma unroll
@@ -492,20 +531,20 @@ k_part_pass(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
         if (rank[e] == EMPTY) continue;
         const uint64_t at = (uint64_t)gbase[bk[e]] + rank[e];
         if (at >= cap_out) continue;                            // overflow: flagged above, the host starts over in table form
-        const uint64_t o = ((uint64_t)p * NB + bk[e]) * cap_out + at;
+        const uint64_t o = (((uint64_t)po * NB + bk[e]) * gmul + grp) * cap_out + at;
+#if MG_PT_EXP == 1
+        if (tk[idx * 2] == 0x1234567ull && tcnt[idx] == 77) keys_out[o * 2] = 1;
+#else
         keys_out[o * 2] = tk[idx * 2]; keys_out[o * 2 + 1] = tk[idx * 2 + 1];
         wt_out[o] = tcnt[idx];
-    }
-    if (!more) break;
-    base += step;
-    __syncthreads();                                            // the LDS tile is rewritten
+#endif
     }
 }
-__global__ void __launch_bounds__(PT_BLOCK)
+__global__ void __launch_bounds__(PT_FBLOCK)
 k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ wt_in, const unsigned long long* __restrict__ n_in,
             const uint32_t* __restrict__ gslots, uint32_t gmask, uint64_t* ukeys, uint32_t U0,
             uint32_t* coo_g, uint32_t* coo_c, unsigned long long* ctr,
-            uint32_t* ll_short, uint32_t* ll_long, unsigned long long* ll_n, int ll_split) {
+            uint32_t* ll_short, uint32_t* ll_long, unsigned long long* ll_n, int ll_split, uint32_t cs_in) {
     // ll_* (nullable): the new uniques' ids by length class, appended to two dense lists (ll_n = their lengths) --
     // those shorter than ll_split nt and the others.  Rounds 1 and 2 of the reference cascade take one length class each
     // (miRge.pl:326): walking "their" list they run with full lanes instead of a third / two thirds of every wave's.
@@ -515,26 +554,27 @@ k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
     __shared__ uint64_t tk[PT_C2 * 2];
     __shared__ uint32_t towner[2 * PT_C2];
     __shared__ uint32_t tcnt[PT_C2];
-    __shared__ uint32_t s_scan[PT_BLOCK / 64];
+    __shared__ uint32_t s_scan[PT_FBLOCK / 64];
     __shared__ uint32_t s_base[2];
-    constexpr int PER = PT_C2 / PT_BLOCK;
+    constexpr int PER = PT_C2 / PT_FBLOCK;
     const uint32_t tid = threadIdx.x, q = blockIdx.x;
-    const uint32_t nvalid = (uint32_t)(n_in[q] < (unsigned long long)PT_C2 ? n_in[q] : (unsigned long long)PT_C2);
+    const unsigned long long nq = n_in[(uint64_t)q * cs_in];
+    const uint32_t nvalid = (uint32_t)(nq < (unsigned long long)PT_C2 ? nq : (unsigned long long)PT_C2);
     if (nvalid == 0) return;
     const uint64_t* kin = keys_in + (uint64_t)q * PT_C2 * 2;
     const uint32_t* win = wt_in + (uint64_t)q * PT_C2;
     uint32_t wcur[PER];                                          // the records' counts, fetched with the keys (as in k_part_pass)
 #pragma unroll
-    for (int e = 0; e < PER; ++e) { const uint32_t idx = tid + e * PT_BLOCK; wcur[e] = idx < nvalid ? win[idx] : 0u; }
-    for (uint32_t j = tid; j < nvalid * 2; j += PT_BLOCK) tk[j] = kin[j];
-    for (uint32_t j = tid; j < 2u * PT_C2; j += PT_BLOCK) towner[j] = EMPTY;
-    for (uint32_t j = tid; j < (uint32_t)PT_C2; j += PT_BLOCK) tcnt[j] = 0;
+    for (int e = 0; e < PER; ++e) { const uint32_t idx = tid + e * PT_FBLOCK; wcur[e] = idx < nvalid ? win[idx] : 0u; }
+    for (uint32_t j = tid; j < nvalid * 2; j += PT_FBLOCK) tk[j] = kin[j];
+    for (uint32_t j = tid; j < 2u * PT_C2; j += PT_FBLOCK) towner[j] = EMPTY;
+    for (uint32_t j = tid; j < (uint32_t)PT_C2; j += PT_FBLOCK) tcnt[j] = 0;
     if (tid < 2) s_lcnt[tid] = 0;
     __syncthreads();
     uint32_t trep[PER];
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
-        const uint32_t idx = tid + e * PT_BLOCK;
+        const uint32_t idx = tid + e * PT_FBLOCK;
         trep[e] = EMPTY;
         if (idx < nvalid) {
             uint64_t k[2] = {tk[idx * 2], tk[idx * 2 + 1]};
@@ -555,7 +595,7 @@ k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
     uint32_t nrep = 0, nnew = 0;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
-        const uint32_t idx = tid + e * PT_BLOCK;
+        const uint32_t idx = tid + e * PT_FBLOCK;
         g[e] = EMPTY; lrank[e] = 0;
         const bool rep = idx < nvalid && trep[e] == idx;
         if (rep && gslots) {
@@ -598,21 +638,29 @@ k_part_fold(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ w
     {
         uint32_t before = 0;
 #pragma unroll
-        for (int w = 0; w < PT_BLOCK / 64; ++w) before += w < (int)(tid >> 6) ? s_scan[w] : 0u;
+        for (int w = 0; w < PT_FBLOCK / 64; ++w) before += w < (int)(tid >> 6) ? s_scan[w] : 0u;
         incl += before;
     }
-    if (tid == PT_BLOCK - 1) {
+    if (tid == PT_FBLOCK - 1) {
         const uint32_t trp = incl & 0xFFFF, tnw = incl >> 16;
+#if MG_PT_EXP == 5
+        const unsigned long long old = ((unsigned long long)(q * 600u) << 32) | (q * 600u); (void)trp; (void)tnw;
+#else
         const unsigned long long old = atomicAdd(&ctr[0], ((unsigned long long)tnw << 32) | trp);
+#endif
         s_base[0] = (uint32_t)old; s_base[1] = (uint32_t)(old >> 32);
     }
-    if (ll_short && tid < 2) s_lbase[tid] = s_lcnt[tid] ? (uint32_t)atomicAdd(&ll_n[tid], (unsigned long long)s_lcnt[tid]) : 0u;   // (s_lcnt is complete: the scan's barriers lie behind)
+#if MG_PT_EXP == 5
+    if (ll_short && tid < 2) s_lbase[tid] = q * 300u;
+#else
+    if (ll_short && tid < 2) s_lbase[tid] = s_lcnt[tid] ? (uint32_t)atomicAdd(&ll_n[tid * LL_CSTRIDE], (unsigned long long)s_lcnt[tid]) : 0u;
+#endif   // (s_lcnt is complete: the scan's barriers lie behind)
     __syncthreads();
     uint32_t prep = s_base[0] + (incl & 0xFFFF) - nrep, pnew = s_base[1] + (incl >> 16) - nnew;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
         if (trep[e] == EMPTY) continue;
-        const uint32_t idx = tid + e * PT_BLOCK;
+        const uint32_t idx = tid + e * PT_FBLOCK;
         uint32_t gg = g[e];
         if (gg == EMPTY) {
             gg = U0 + pnew++;

@@ -553,19 +553,24 @@ bool part_wanted(uint64_t n) {
     if (const char* e = getenv("MIRGE_PART_MAX")) hi = strtoull(e, nullptr, 10);
     return n >= lo && n <= hi;
 }
-// blocks of a split-pass launch: one per tile.  (MIRGE_PART_GRID = N: tuning aid, N blocks that stride over the tiles
-// with the next tile on its way into registers -- measured 0.52 ms for both passes at two blocks per CU against 0.47:
-// blocks that come and go overlap better than resident ones that prefetch.)
-inline uint32_t part_grid() {
-    if (const char* e = getenv("MIRGE_PART_GRID")) { const long v = atol(e); if (v > 0) return (uint32_t)v; }
-    return 0xFFFFFFFFu;
-}
 // fan-out of the first pass: the fewest final partitions (P1 x PT_P2 of them, PT_C2 records each at most) that come out
 // at most ~75 % full when every read is distinct (hashed keys: 2048 is then 13 sigma above the mean).  Fewest, because
 // every partition ends in one atomic on the table's rank counter and those are served one after the other (~12 ns):
 // at 100M reads the fold kernel took 1.68 ms with 131 K partitions -- exactly that chain.
 inline uint64_t part_fill() { if (const char* e = getenv("MIRGE_PART_FILL")) { const long v = atol(e); if (v >= 100000 && v <= 500000) return (uint64_t)v; } return 390000; }     // reads per first-pass bucket (tuning aid)
 int part_p1(uint64_t n) { return (int)std::min<uint64_t>(512, std::max<uint64_t>(16, (n + part_fill() - 1) / part_fill())); }
+// cursor groups of the first split pass (kernels.h: k_part_pass says what they are for)
+inline uint32_t part_groups(uint64_t n) {
+    if (const char* e = getenv("MIRGE_PART_GROUPS")) { const long v = atol(e); if (v >= 1 && v <= 64) return (uint32_t)v; }
+    return 8;
+}
+// 8-byte words between two cursors of the first pass: every tile of the launch bumps every one of them, and the device
+// serves atomics on one 128-B LINE one after the other (profiles/r03/collapse_experiments.txt: 16 cursors per line 0.269 ms,
+// a line each 0.235, 512 B apart 0.224)
+inline uint32_t part_cstride() {
+    if (const char* e = getenv("MIRGE_PART_CSTRIDE")) { const long v = atol(e); if (v >= 1 && v <= 4096) return (uint32_t)v; }
+    return 64;
+}
 template <int KW>
 int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64, int sample, const char* tagA, const char* tagB,
                     const uint32_t* d_wt = nullptr, bool allow_part = true) {
@@ -577,11 +582,15 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
     hipStream_t st = C.st;
     if (KW == 2 && allow_part && part_wanted(n)) {
         const int PT_P1 = part_p1(n);
-        uint32_t C1 = n / PT_P1 + n / (2 * PT_P1) + PT_TILE;                 // 1.5 x the even share
+        const uint32_t G = part_groups(n);                                   // cursor groups of the first pass (kernels.h: k_part_pass)
+        const uint32_t PG = (uint32_t)PT_P1 * G;                             // regions the first pass writes = input partitions of the second
+        uint32_t C1 = n / PG + n / (2 * PG) + PT_TILE2;                      // 1.5 x the even share
         if (const char* e = getenv("MIRGE_PART_C1")) C1 = (uint32_t)std::max(1, atoi(e));       // tests: force an overrun
-        const size_t ncur = (size_t)PT_P1 + (size_t)PT_P1 * PT_P2 + 1;
-        HIPCHK(c, C.pt_k1.ensure((size_t)PT_P1 * C1 * 16, false, 0, st));
-        HIPCHK(c, C.pt_w1.ensure((size_t)PT_P1 * C1 * 4, false, 0, st));
+        const uint32_t CS = part_cstride();                                  // 8-byte words between two cursors of the first pass
+        const uint32_t CS2 = 1;                                              // ... of the second pass: dense (16 to a line: its 256 atomics per tile touch fewer lines; a line each 0.216 against 0.193 ms)
+        const size_t ncur = (size_t)PG * CS + (size_t)PT_P1 * PT_P2 * CS2 + 1;
+        HIPCHK(c, C.pt_k1.ensure((size_t)PG * C1 * 16, false, 0, st));
+        HIPCHK(c, C.pt_w1.ensure((size_t)PG * C1 * 4, false, 0, st));
         HIPCHK(c, C.pt_k2.ensure((size_t)PT_P1 * PT_P2 * PT_C2 * 16, false, 0, st));
         HIPCHK(c, C.pt_w2.ensure((size_t)PT_P1 * PT_P2 * PT_C2 * 4, false, 0, st));
         HIPCHK(c, C.pt_cur.ensure(ncur * 8, false, 0, st));
@@ -606,27 +615,28 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
         HIPCHK(c, hipMemsetAsync(C.ws_ctr.p, 0, 64, st));
         if (C.ll_ok) {
             for (auto& b : C.ll) HIPCHK(c, b.ensure((C.U + n) * 4, true, C.U * 4, st));
-            HIPCHK(c, C.ll_ctr.ensure(64, false, 0, st));
-            if (!C.ll_fresh) { HIPCHK(c, hipMemsetAsync(C.ll_ctr.p, 0, 64, st)); C.ll_fresh = true; }
+            HIPCHK(c, C.ll_ctr.ensure(LL_CSTRIDE * 16, false, 0, st));
+            if (!C.ll_fresh) { HIPCHK(c, hipMemsetAsync(C.ll_ctr.p, 0, LL_CSTRIDE * 16, st)); C.ll_fresh = true; }
         }
         unsigned long long* cur = C.pt_cur.as<unsigned long long>();
         unsigned long long* ovf = cur + ncur - 1;
         kt_begin(c, "collapse_part16", st);
-        auto pass1 = PT_P1 <= 16 ? k_part_pass<16> : PT_P1 <= 32 ? k_part_pass<32> : PT_P1 <= 64 ? k_part_pass<64> : PT_P1 <= 128 ? k_part_pass<128> : PT_P1 <= 256 ? k_part_pass<256> : k_part_pass<512>;      // (NB = LDS counters: any fan-out up to it)
-        const uint32_t g1 = std::min<uint32_t>((n + PT_TILE - 1) / PT_TILE, part_grid());
-        const uint32_t g2 = std::min<uint32_t>((C1 + PT_TILE - 1) / PT_TILE, std::max<uint32_t>(1, part_grid() / PT_P1));
-        hipLaunchKernelGGL(pass1, dim3(g1, 1), dim3(PT_BLOCK), 0, st, d_keys, d_wt,
-                           (const unsigned long long*)nullptr, n, 0u, (uint32_t)PT_P1, 0, C.pt_k1.as<uint64_t>(), C.pt_w1.as<uint32_t>(), cur, C1, ovf);
-        hipLaunchKernelGGL((k_part_pass<PT_P2>), dim3(g2, PT_P1), dim3(PT_BLOCK), 0, st, C.pt_k1.as<uint64_t>(),
+#define MG_PASS1(NB) k_part_pass<NB, PT_TILE1, PT_BLOCK1>
+        auto pass1 = PT_P1 <= 16 ? MG_PASS1(16) : PT_P1 <= 32 ? MG_PASS1(32) : PT_P1 <= 64 ? MG_PASS1(64) : PT_P1 <= 128 ? MG_PASS1(128) : PT_P1 <= 256 ? MG_PASS1(256) : MG_PASS1(512);      // (NB = LDS counters: any fan-out up to it)
+#undef MG_PASS1
+        const uint32_t g1 = (n + PT_TILE1 - 1) / PT_TILE1, g2 = (C1 + PT_TILE2 - 1) / PT_TILE2;      // a block per tile
+        hipLaunchKernelGGL(pass1, dim3(g1, 1), dim3(PT_BLOCK1), 0, st, d_keys, d_wt,
+                           (const unsigned long long*)nullptr, n, 0u, (uint32_t)PT_P1, 0, C.pt_k1.as<uint64_t>(), C.pt_w1.as<uint32_t>(), cur, C1, ovf, G, 1u, 1u, CS);
+        hipLaunchKernelGGL((k_part_pass<PT_P2, PT_TILE2, PT_BLOCK2>), dim3(g2, PG), dim3(PT_BLOCK2), 0, st, C.pt_k1.as<uint64_t>(),
                            C.pt_w1.as<uint32_t>(), (const unsigned long long*)cur, C1, C1, (uint32_t)PT_P1, 1, C.pt_k2.as<uint64_t>(), C.pt_w2.as<uint32_t>(),
-                           cur + PT_P1, (uint32_t)PT_C2, ovf);
+                           cur + (size_t)PG * CS, (uint32_t)PT_C2, ovf, 1u, G, CS, CS2);
         kt_end(c, "collapse_part16", (uint64_t)n * 16, st);
         kt_begin(c, "collapse_fold16", st);
-        hipLaunchKernelGGL(k_part_fold, dim3(PT_P1 * PT_P2), dim3(PT_BLOCK), 0, st, C.pt_k2.as<uint64_t>(), C.pt_w2.as<uint32_t>(),
-                           (const unsigned long long*)(cur + PT_P1), use_g ? C.gslots.as<uint32_t>() : (const uint32_t*)nullptr,
+        hipLaunchKernelGGL(k_part_fold, dim3(PT_P1 * PT_P2), dim3(PT_FBLOCK), 0, st, C.pt_k2.as<uint64_t>(), C.pt_w2.as<uint32_t>(),
+                           (const unsigned long long*)(cur + (size_t)PG * CS), use_g ? C.gslots.as<uint32_t>() : (const uint32_t*)nullptr,
                            (uint32_t)(C.gcap ? C.gcap - 1 : 0), C.ukeys.as<uint64_t>(), (uint32_t)C.U,
                            C.coo_g.as<uint32_t>() + C.coo_n, C.coo_c.as<uint32_t>() + C.coo_n, C.ws_ctr.as<unsigned long long>(),
-                           C.ll_ok ? C.ll[0].as<uint32_t>() : (uint32_t*)nullptr, C.ll[1].as<uint32_t>(), C.ll_ctr.as<unsigned long long>(), LL_SPLIT);
+                           C.ll_ok ? C.ll[0].as<uint32_t>() : (uint32_t*)nullptr, C.ll[1].as<uint32_t>(), C.ll_ctr.as<unsigned long long>(), LL_SPLIT, CS2);
         kt_end(c, "collapse_fold16", 0, st);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(C.h_ctr, C.ws_ctr.p, 16, hipMemcpyDeviceToHost, st));
@@ -1256,7 +1266,7 @@ void launch_match(mirge_ctx* c, Class& C, const RoundDev& P, const LibDev& L, in
     unsigned long long* const cnt_in = C.act_n + (size_t)r * LIST_K * LIST_NSTRIDE;
     unsigned long long* const cnt_out = C.act_n + (size_t)(r + 1) * LIST_K * LIST_NSTRIDE;
     ListIn in{nullptr, nullptr, 0, 0};
-    if (r <= 1) { if (ll) in = ListIn{C.ll[r].as<uint32_t>(), C.ll_ctr.as<unsigned long long>() + r, 1, 0}; }
+    if (r <= 1) { if (ll) in = ListIn{C.ll[r].as<uint32_t>(), C.ll_ctr.as<unsigned long long>() + r * LL_CSTRIDE, 1, 0}; }
     else if (!(r == 2 && ll)) in = ListIn{C.act[(r + 1) & 1].as<uint32_t>(), cnt_in, C.lf[r].K, C.lf[r].cap};
     const bool writes = (ll ? r >= 2 : r >= 1) && r + 1 < c->n_rounds;
     const bool init = r == 0 || (r == 1 && ll);
