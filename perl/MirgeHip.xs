@@ -83,6 +83,26 @@ mirge_collapse_raw_fastq(ctx, path, sample, adapter, trim5, trim3)
         PUSHs(sv_2mortal(newSViv((IV)phred)));
 
 void
+mirge_collapse_fastq_batch(ctx, paths, adapter, trim5, trim3)
+        MirgeHip ctx
+        AV* paths
+        SV* adapter
+        int trim5
+        int trim3
+    PREINIT:
+        int n, i; const char** fp; int32_t* smp; uint64_t *tot, *kept; int32_t* ph; int rc;
+    PPCODE:
+        /* the per-sample loop of runQuantitationPipeline (miRge.pl:243-266) as one call: file i is sample i, files are read /
+           inflated ahead by host threads; adapter undef = trimmed files.  Returns (total_0, kept_0, phred_0, total_1, ...) */
+        n = (int)(av_len(paths) + 1);
+        Newx(fp, n ? n : 1, const char*); Newx(smp, n ? n : 1, int32_t); Newx(tot, n ? n : 1, uint64_t); Newx(kept, n ? n : 1, uint64_t); Newx(ph, n ? n : 1, int32_t);
+        for (i = 0; i < n; ++i) { SV** e = av_fetch(paths, i, 0); fp[i] = e ? SvPV_nolen(*e) : ""; smp[i] = i; tot[i] = kept[i] = 0; ph[i] = 33; }
+        rc = mirge_collapse_fastq_batch(ctx, n, fp, smp, SvOK(adapter) ? SvPV_nolen(adapter) : NULL, trim5, trim3, tot, kept, ph);
+        if (rc == MIRGE_OK) { EXTEND(SP, 3 * n); for (i = 0; i < n; ++i) { mPUSHu((UV)tot[i]); mPUSHu((UV)kept[i]); mPUSHi((IV)ph[i]); } }
+        Safefree(fp); Safefree(smp); Safefree(tot); Safefree(kept); Safefree(ph);
+        if (rc != MIRGE_OK) croak("MirgeHip::collapse_fastq_batch: %s", mirge_last_error(ctx));
+
+void
 mirge_annotate(ctx)
         MirgeHip ctx
     CODE:

@@ -34,7 +34,12 @@ if (defined $grp) {
     my @r = MirgeHip::group_collapse_fastq_batch($grp, \@fastq, $adapter, $trim5, $trim3);
     $trimmedReads[$_] = $r[3 * $_ + 1] for (0 .. $S - 1);
 }
-for (my $i = 0; $i < $S && !defined $grp; $i++) {
+my $batched = !defined $grp && defined $out && $S > 1;                  # several files: one call, files read / inflated ahead by host threads
+if ($batched) {
+    my @r = MirgeHip::collapse_fastq_batch($ctx, \@fastq, $adapter, $trim5, $trim3);
+    $trimmedReads[$_] = $r[3 * $_ + 1] for (0 .. $S - 1);
+}
+for (my $i = 0; $i < $S && !defined $grp && !$batched; $i++) {
     if (defined $adapter) {                                          # trimRaw + cutadapt -u + quantReads, miRge.pl:259-262
         my ($total, $kept, $phred) = MirgeHip::collapse_raw_fastq($ctx, $fastq[$i], $i, $adapter, $trim5, $trim3);
         $trimmedReads[$i] = $kept;

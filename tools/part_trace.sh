@@ -9,7 +9,7 @@ for lib in "$@"; do
 import csv, sys, re
 out = []
 for r in csv.DictReader(open(sys.argv[2])):
-    m = re.search(r"k_part_(pass<\d+>|fold)", r["Name"])
+    m = re.search(r"k_part_(pass<[\d, ]+>|fold)", r["Name"])
     if m: out.append("%s %.1f us (min %.1f, n=%s)" % (m.group(1), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, r["Calls"]))
 print("%-28s %s" % (sys.argv[1], " | ".join(sorted(out))))
 PY

@@ -12,7 +12,7 @@ for cfg in "$@"; do
 import csv, sys, re, json
 out = []
 for r in csv.DictReader(open(sys.argv[2])):
-    m = re.search(r"k_part_(pass<\d+>|fold)", r["Name"])
+    m = re.search(r"k_part_(pass<[\d, ]+>|fold)", r["Name"])
     if m: out.append("%s %.1f us (min %.1f, n=%s)" % (m.group(1), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, r["Calls"]))
 d = json.load(open(sys.argv[3]))
 print("%-28s %s | inv=%s" % (sys.argv[1], " | ".join(sorted(out)), d.get("invariants_full_size")))
