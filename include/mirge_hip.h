@@ -115,9 +115,11 @@ int32_t     mirge_collapse_fastq_dev(mirge_ctx*, const void* d_data, uint64_t si
  * trim_file.py:26-68) runs on the device between record splitting and packing: 3' quality trimming (cutoff 10),
  * 3' adapter removal (error rate 0.12, overlap >= 3) or an unconditional cut, length >= 16 filter, then trim5 / trim3
  * bases off the ends.  adapter as miRge.pl's --adapter: "none", "illumina", "ion", "+N" / "-N", or up to 16 comma-separated
- * 3' adapter sequences as cutadapt's -a takes them (trim_file.py:14-23): A/C/G/T/U in either case, <= 64 nt, optionally
- * "name=SEQUENCE", a trailing "$" anchors the adapter at the read's 3' end.  IUPAC wildcards in an adapter, 5' and
- * linked adapters are refused (MIRGE_E_ARG).  total_reads / trimmed_reads = logHash totalReads / trimmedReads
+ * 3' adapter sequences as cutadapt's -a takes them (trim_file.py:14-23): A/C/G/T/U and the IUPAC wildcard codes (R Y S W
+ * K M B D H V N X: cutadapt's adapter_wildcards -- an adapter N matches any read base, a read N nothing) in either case,
+ * <= 64 nt, optionally "name=SEQUENCE", a trailing "$" anchors the adapter at the read's 3' end.  Linked adapters
+ * (A...B, cutadapt >= 1.10) and brace repeats are refused (MIRGE_E_ARG); 5' adapters cannot be asked for through
+ * miRge (trim_file.py hands every adapter over as a 3' one).  total_reads / trimmed_reads = logHash totalReads / trimmedReads
  * (miRge.pl:285-288); phred = the value trim_file.py prints (33 or 64).  Raw lines of up to MIRGE_MAX_READ_LEN
  * characters: a line no key holds (150-nt reads with the adapter still on, lower case ...) is trimmed on its bytes.
  * The quality and adapter algorithms are cutadapt's (third party): parity with it is unpinned, see DESIGN.md. */

@@ -39,7 +39,7 @@ std::string rccl_load() {
     if (g_rccl.h) return "";
     void* h = nullptr;
     for (const char* nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (h) break; }
-    if (!h) return std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+    if (!h) { const char* why = dlerror(); return std::string("cannot load RCCL: ") + (why ? why : "librccl.so.1 not found"); }      // (dlerror() clears itself: one call)
     Rccl r; r.h = h;
 #define MG_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name)); if (!r.field) { dlclose(h); return std::string("RCCL lacks ") + name; }
     MG_SYM(CommInitAll, "ncclCommInitAll") MG_SYM(CommDestroy, "ncclCommDestroy") MG_SYM(GroupStart, "ncclGroupStart") MG_SYM(GroupEnd, "ncclGroupEnd")
@@ -138,7 +138,7 @@ int collapse_files(mirge_ctx* c, const std::vector<int>& idx, const char* const*
     if (hipSetDevice(c->device) != hipSuccess) rc = fail(c, MIRGE_E_HIP, "hipSetDevice failed");
     for (size_t i = 0; i < m && rc == MIRGE_OK; ++i) {
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return state[i] != 0; }); }
-        if (state[i] < 0) { rc = fail(c, MIRGE_E_IO, errs[i]); break; }
+        if (state[i] < 0) { rc = fail(c, errs[i].compare(0, 12, "FASTQ upload") == 0 ? MIRGE_E_HIP : MIRGE_E_IO, errs[i]); break; }
         const int j = idx[i];
         const uint64_t size = dsize[i];
         const uint8_t last = dlast[i];
@@ -247,16 +247,19 @@ int group_merge(mirge_group* g) {
         std::vector<std::vector<uint64_t>> at((size_t)W, std::vector<uint64_t>((size_t)W, 0));
         for (int r = 0; r < W; ++r) for (int d = 0; d < W; ++d) { at[(size_t)r][(size_t)d] = roff[(size_t)d]; roff[(size_t)d] += n[(size_t)r][(size_t)d] * rec; }
         NCCLCHK(g, g_rccl.GroupStart());
-        for (int r = 0; r < W; ++r) {
+        ncclResult_t bad = ncclSuccess;                               // (a failed call must not leave the group open: ncclGroupEnd runs whatever happens)
+        for (int r = 0; r < W && bad == ncclSuccess; ++r) {
             uint64_t soff = 0;
-            for (int d = 0; d < W; ++d) {
+            for (int d = 0; d < W && bad == ncclSuccess; ++d) {
                 const uint64_t sb = n[(size_t)r][(size_t)d] * rec, rb = n[(size_t)d][(size_t)r] * rec;
-                if (sb) NCCLCHK(g, g_rccl.Send(snd[(size_t)r].as<uint8_t>() + soff, (size_t)sb, ncclUint8, d, g->comm[(size_t)r], g->ctx[(size_t)r]->st));
-                if (rb) NCCLCHK(g, g_rccl.Recv(rcv[(size_t)r].as<uint8_t>() + at[(size_t)d][(size_t)r], (size_t)rb, ncclUint8, d, g->comm[(size_t)r], g->ctx[(size_t)r]->st));
+                if (sb) bad = g_rccl.Send(snd[(size_t)r].as<uint8_t>() + soff, (size_t)sb, ncclUint8, d, g->comm[(size_t)r], g->ctx[(size_t)r]->st);
+                if (rb && bad == ncclSuccess) bad = g_rccl.Recv(rcv[(size_t)r].as<uint8_t>() + at[(size_t)d][(size_t)r], (size_t)rb, ncclUint8, d, g->comm[(size_t)r], g->ctx[(size_t)r]->st);
                 soff += sb;
             }
         }
-        NCCLCHK(g, g_rccl.GroupEnd());
+        const ncclResult_t ended = g_rccl.GroupEnd();
+        if (bad != ncclSuccess) return gfail(g, MIRGE_E_HIP, std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(bad));
+        NCCLCHK(g, ended);
         for (int r = 0; r < W; ++r)
             if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess || hipStreamSynchronize(g->ctx[(size_t)r]->st) != hipSuccess) return gfail(g, MIRGE_E_HIP, "all-to-all failed");
         return MIRGE_OK;
@@ -308,8 +311,11 @@ int group_allreduce(mirge_group* g) {
             if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess || hipMemcpy(g->flat[(size_t)r].p, sum.data(), len * 8, hipMemcpyHostToDevice) != hipSuccess) return gfail(g, MIRGE_E_HIP, "host-staged all-reduce failed");
     } else {
         NCCLCHK(g, g_rccl.GroupStart());
-        for (int r = 0; r < W; ++r) NCCLCHK(g, g_rccl.AllReduce(g->flat[(size_t)r].p, g->flat[(size_t)r].p, (size_t)len, ncclUint64, ncclSum, g->comm[(size_t)r], g->ctx[(size_t)r]->st));
-        NCCLCHK(g, g_rccl.GroupEnd());
+        ncclResult_t bad = ncclSuccess;
+        for (int r = 0; r < W && bad == ncclSuccess; ++r) bad = g_rccl.AllReduce(g->flat[(size_t)r].p, g->flat[(size_t)r].p, (size_t)len, ncclUint64, ncclSum, g->comm[(size_t)r], g->ctx[(size_t)r]->st);
+        const ncclResult_t ended = g_rccl.GroupEnd();
+        if (bad != ncclSuccess) return gfail(g, MIRGE_E_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(bad));
+        NCCLCHK(g, ended);
         for (int r = 0; r < W; ++r)
             if (hipSetDevice(g->dev[(size_t)r]) != hipSuccess || hipStreamSynchronize(g->ctx[(size_t)r]->st) != hipSuccess) return gfail(g, MIRGE_E_HIP, "all-reduce failed");
     }
@@ -402,7 +408,7 @@ int32_t mirge_group_collapse_seqs(mirge_group* g, const char* seqs, const uint64
 int32_t mirge_group_collapse_fastq_batch(mirge_group* g, int32_t n, const char* const* paths, const int32_t* samples, const char* adapter,
                                          int32_t trim5, int32_t trim3, uint64_t* total_reads, uint64_t* trimmed_reads, int32_t* phred) {
     if (!g || n < 0 || (n && (!paths || !samples))) return g ? gfail(g, MIRGE_E_ARG, "null input") : MIRGE_E_ARG;
-    for (int i = 0; i < n; ++i) if (samples[i] < 0 || samples[i] >= g->S) return gfail(g, MIRGE_E_ARG, "sample index out of range");
+    for (int i = 0; i < n; ++i) if (samples[i] < 0 || samples[i] >= g->S || !paths[i]) return gfail(g, MIRGE_E_ARG, "sample index out of range or null path");
     g->merged = false; g->annotated = false;
     const int W = g->world, per = std::max(1, host_threads() / W);
     return group_parallel(g, [&](int r) {

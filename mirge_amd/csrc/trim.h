@@ -30,7 +30,9 @@ struct TrimDev {
     int32_t alen[TRIM_MAX_ADAPTERS];
     uint32_t anchored;                     // bit ad: the adapter was written "ADAPTER$" (must end at the read's 3' end)
     int32_t max_alen;
-    uint64_t acode[TRIM_MAX_ADAPTERS][2];  // 2-bit codes, adapter nt i at bits 2i of the 128-bit value
+    uint64_t acode[TRIM_MAX_ADAPTERS][2];  // 2-bit codes, adapter nt i at bits 2i of the 128-bit value (plain adapters: the exact-occurrence search)
+    uint64_t amask[TRIM_MAX_ADAPTERS][4];  // 4 bits per adapter nt: the bases it stands for (A = bit 0 .. T = bit 3; IUPAC codes several, N all, X none)
+    uint32_t wild;                         // bit ad: the adapter holds a character outside ACGT (cutadapt's adapter_wildcards are then in force)
     int32_t base;                          // phred base of the quality trimmer
     int32_t trim5, trim3, min_len, min_overlap;
     int8_t  maxerr[TRIM_MAX_ALEN + 1];     // [len] = largest cost with (double)cost <= len * rate   (host, in double)
@@ -69,13 +71,20 @@ inline int trim_dev_from_spec(const char* adapter, int trim5, int trim3, TrimDev
         if (one.empty()) continue;
         if (T.n_ad >= TRIM_MAX_ADAPTERS) { msg = "more than " + std::to_string(TRIM_MAX_ADAPTERS) + " adapters"; return -5; }
         if ((int)one.size() > TRIM_MAX_ALEN) { msg = "adapter longer than " + std::to_string(TRIM_MAX_ALEN) + " nt"; return -5; }
+        if (one.find("...") != std::string::npos) { msg = "adapter '" + one + "': linked adapters (ADAPTER1...ADAPTER2, cutadapt >= 1.10) are not supported"; return -1; }
         for (size_t i = 0; i < one.size(); ++i) {
             uint8_t ch = (uint8_t)one[i];
             if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32);
             if (ch == 'U') ch = 'T';
-            int b = base_code(ch);
-            if (b < 0 || b > 3) { msg = "adapter '" + one + "': 3' adapters of A, C, G, T (plain, or anchored with a trailing $) are supported; IUPAC wildcards, 5' and linked adapters are not"; return -1; }
-            T.acode[T.n_ad][i >> 5] |= (uint64_t)b << (2 * (i & 31));
+            // the IUPAC table of cutadapt's aligner: a bit per base the character stands for
+            static const char* codes = "ACGTRYSWKMBDHVNX";
+            static const uint8_t bits[16] = {1, 2, 4, 8, 1 | 4, 2 | 8, 2 | 4, 1 | 8, 4 | 8, 1 | 2, 2 | 4 | 8, 1 | 4 | 8, 1 | 2 | 8, 1 | 2 | 4, 15, 0};
+            const char* at = ch ? strchr(codes, (int)ch) : nullptr;
+            if (!at) { msg = "adapter '" + one + "': 3' adapters of A, C, G, T and IUPAC wildcard codes (plain, or anchored with a trailing $) are supported; braces, 5' and linked adapters are not"; return -1; }
+            const int ci = (int)(at - codes);
+            if (ci < 4) T.acode[T.n_ad][i >> 5] |= (uint64_t)ci << (2 * (i & 31));
+            else T.wild |= 1u << T.n_ad;
+            T.amask[T.n_ad][i >> 4] |= (uint64_t)bits[ci] << (4 * (i & 15));
         }
         if (anchored) T.anchored |= 1u << T.n_ad;
         T.alen[T.n_ad] = (int32_t)one.size(); T.max_alen = std::max<int32_t>(T.max_alen, (int32_t)one.size()); ++T.n_ad;
@@ -111,13 +120,17 @@ MG_HD int c_origin(uint32_t c) { return (int)(c & 0xFFFF); }
 // Adapter `ad` against read nts [a, b): true if it matches; rstart (relative to a) and matches out.
 // col: this lane's DP column, cell i at col[i * stride].
 MG_HD int ad_code(const TrimDev& T, int ad, int i) { return (int)((T.acode[ad][i >> 5] >> (2 * (i & 31))) & 3); }
+// does adapter nt i stand for the read base of code c (cutadapt: the two characters' bit sets meet)
+MG_HD bool ad_eq(const TrimDev& T, int ad, int i, int c) { return (T.amask[ad][i >> 4] >> (4 * (i & 15) + c)) & 1; }
 template <class Acc>
 MG_HD bool adapter_match(const TrimDev& T, int ad, const Acc& rd, int a, int b,
                          uint32_t* col, int stride, int& rstart, int& matches_out) {
     const int m = T.alen[ad], n = b - a;
     const bool anch = (T.anchored >> ad) & 1u;
-    // exact occurrence first: the leftmost one (anchored: only as the read's suffix)
-    if (m <= 32 && !anch) {
+    // exact occurrence first: the leftmost one (anchored: only as the read's suffix) -- unless the adapter holds
+    // wildcards (Adapter.match_to: "try to find an exact match first unless wildcards are allowed")
+    if ((T.wild >> ad) & 1u) {
+    } else if (m <= 32 && !anch) {
         // rolling 2m-bit window over the read
         const uint64_t ac = T.acode[ad][0];
         const uint64_t full = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1);
@@ -149,7 +162,7 @@ MG_HD bool adapter_match(const TrimDev& T, int ad, const Acc& rd, int a, int b,
         col[0] = up;
         for (int i = 1; i <= last; ++i) {
             const uint32_t cur = col[i * stride];
-            const bool eq = !nj && ad_code(T, ad, i - 1) == cj;
+            const bool eq = !nj && ad_eq(T, ad, i - 1, cj);
             uint32_t nw;
             if (eq) nw = cell(c_cost(tmp), c_matches(tmp) + 1, c_origin(tmp));
             else {

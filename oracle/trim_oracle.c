@@ -16,7 +16,9 @@
  * 3' ("back") adapter = leftmost exact occurrence first, else Aligner.locate (semiglobal edit-distance DP with
  * Ukkonen's band, flags START_WITHIN_SEQ2 | STOP_WITHIN_SEQ2 | STOP_WITHIN_SEQ1, best = most matches, then lowest cost,
  * error bound cost <= aligned_adapter_length * rate evaluated in double, min overlap 3), AdapterCutter (times = 1, best
- * adapter = most matches, first wins ties), UnconditionalCutter.
+ * adapter = most matches, first wins ties), UnconditionalCutter.  Adapters with IUPAC wildcard characters: see
+ * chars_equal below (no exact-occurrence shortcut for them; error bound on the full aligned length, as in 1.9-1.11 --
+ * later versions discount N positions).
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -46,11 +48,38 @@ void orc_quality_trim(const char* q, int n, int cutoff_front, int cutoff_back, i
 
 typedef struct { int cost, matches, origin; } Entry;
 
+/* Adapter wildcards (cutadapt Adapter(..., adapter_wildcards=True), the default: active when the adapter holds a character
+ * outside ACGT).  align.pyx: the adapter is translated with the IUPAC table (a bit per base it stands for), the read with
+ * the ACGT table (every other character 0), and two characters are equal when their codes share a bit -- so an adapter N
+ * matches any read base, a read N (or any other non-base) matches nothing, X matches nothing. */
+static int iupac_bits(int ch) {
+    switch (ch) {
+        case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': case 'U': return 8;
+        case 'R': return 1 | 4; case 'Y': return 2 | 8; case 'S': return 2 | 4; case 'W': return 1 | 8;
+        case 'K': return 4 | 8; case 'M': return 1 | 2; case 'B': return 2 | 4 | 8; case 'D': return 1 | 4 | 8;
+        case 'H': return 1 | 2 | 8; case 'V': return 1 | 2 | 4; case 'N': return 15; case 'X': return 0;
+        default: return -1;
+    }
+}
+static int acgt_bits(int ch) { return ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 4 : ch == 'T' ? 8 : 0; }
+static int chars_equal(int adapter_ch, int read_ch, int wildcards) {
+    return wildcards ? (iupac_bits(adapter_ch) & acgt_bits(read_ch)) != 0 : adapter_ch == read_ch;
+}
+/* 1 = the adapter holds wildcards, 0 = plain ACGT, -1 = a character cutadapt's parser refuses */
+int orc_adapter_wildcards(const char* adapter, int m) {
+    int wild = 0;
+    for (int i = 0; i < m; ++i) {
+        if (iupac_bits((unsigned char)adapter[i]) < 0) return -1;
+        if (!strchr("ACGT", adapter[i])) wild = 1;
+    }
+    return wild;
+}
+
 /* cutadapt _align.Aligner.locate for a back adapter (reference = adapter, query = read).
  * out = {astart, astop, rstart, rstop, matches, errors}; returns 1 if an alignment qualifies. */
 /* anchored (a 3' adapter written "ADAPTER$": where = SUFFIX, flags = START_WITHIN_SEQ2 alone): the alignment must take in
  * the whole adapter and end at the read's end -- only cell (m, n) is a candidate. */
-static int locate_back(const char* s1, int m, const char* s2, int n, double max_error_rate, int min_overlap, int anchored, int out[6]) {
+static int locate_back(const char* s1, int m, const char* s2, int n, double max_error_rate, int min_overlap, int anchored, int wildcards, int out[6]) {
     Entry column[ORC_TRIM_MAXADAPTER + 1];
     const int k = (int)(max_error_rate * m);
     for (int i = 0; i <= m; ++i) { column[i].matches = 0; column[i].cost = i; column[i].origin = 0; }
@@ -61,7 +90,7 @@ static int locate_back(const char* s1, int m, const char* s2, int n, double max_
         column[0].origin = j;                                    /* the alignment may start anywhere in the read */
         for (int i = 1; i <= last; ++i) {
             int cost, origin, matches;
-            if (s1[i - 1] == s2[j - 1]) {
+            if (chars_equal((unsigned char)s1[i - 1], (unsigned char)s2[j - 1], wildcards)) {
                 cost = tmp.cost; origin = tmp.origin; matches = tmp.matches + 1;
             } else {
                 int cost_diag = tmp.cost + 1, cost_deletion = column[i].cost + 1, cost_insertion = column[i - 1].cost + 1;
@@ -108,13 +137,17 @@ int orc_adapter_back(const char* adapter, int m, const char* read_in, int n, dou
     if (m <= 0 || m > ORC_TRIM_MAXADAPTER || n < 0 || n > 4096) return 0;
     char read[4097];
     for (int i = 0; i < n; ++i) read[i] = (char)toupper((unsigned char)read_in[i]);
-    if (anchored) {
+    const int wildcards = orc_adapter_wildcards(adapter, m);
+    if (wildcards < 0) return 0;
+    if (wildcards) {
+        /* match_to: "try to find an exact match first unless wildcards are allowed" -- straight to the aligner */
+    } else if (anchored) {
         if (n >= m && memcmp(read + n - m, adapter, (size_t)m) == 0) { out[0] = 0; out[1] = m; out[2] = n - m; out[3] = n; out[4] = m; out[5] = 0; return 1; }
     } else {
         for (int p = 0; p + m <= n; ++p)
             if (memcmp(read + p, adapter, (size_t)m) == 0) { out[0] = 0; out[1] = m; out[2] = p; out[3] = p + m; out[4] = m; out[5] = 0; return 1; }
     }
-    if (!locate_back(adapter, m, read, n, max_error_rate, min_overlap, anchored, out)) return 0;
+    if (!locate_back(adapter, m, read, n, max_error_rate, min_overlap, anchored, wildcards, out)) return 0;
     int length = out[1] - out[0];
     if (length < min_overlap || (double)out[5] / length > max_error_rate) return 0;
     return 1;

@@ -34,6 +34,8 @@ def table(ctx):
     # adapter syntax of cutadapt's -a beyond a plain short sequence: anchored, named, lower case, many, long
     (17, A + "$", 0, 0, {}), (18, "small=" + A.lower() + ",ACGTTGCATGCATGCAAGCTTGACGTACGATCGATCGTACGATCGGTTAACC$", 0, 0, {"read_len": 75}),
     (19, ",".join([A[:20]] + ["ACGTTGCAAGCTTGACCA"[i:] + "GATTACA" for i in range(9)]), 0, 0, {}),
+    # IUPAC wildcard characters in the adapter (cutadapt's adapter_wildcards): codes inside it, a random 4-mer (NNNN) in front
+    (20, A[:6] + "R" + A[7:14] + "N" + A[15:22] + "B" + A[23:], 0, 0, {}), (21, "NNNN" + A[4:] + ",TGGAATTCTYGG$", 0, 1, {"read_len": 75, "adapter_error": 0.5}),
 ])
 def test_gpu_equals_restatement(ctx, tmp_path, seed, adapter, t5, t3, kw):
     data = raw_case(seed, n=20000, **kw)
@@ -69,7 +71,7 @@ def test_errors(ctx):
         with pytest.raises(capi.MirgeError) as e:
             ctx.collapse_raw_fastq_mem(data, 0, "none")
         assert e.value.code == code
-    for bad in ("ACGR", "A" * 65, ",".join(["ACGTAC"] * 17)):
+    for bad in ("ACGJ", "ACGT{3}", "ACGTAC...GGTTAA", "A" * 65, ",".join(["ACGTAC"] * 17)):
         with pytest.raises(capi.MirgeError):
             ctx.collapse_raw_fastq_mem(b"", 0, bad)
     ctx.reset()

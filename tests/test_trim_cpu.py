@@ -129,7 +129,8 @@ def test_adapter_syntax_known_answers(hostsim):
     got = sim_trim(hostsim, _fq(reads), spec)
     assert got[0][:3] == [ins[0], ins[1], ins[2]] and got[0] == otrim.trim_fastq(_fq(reads), spec)[0]      # (the adapter-free read may lose a chance 3-nt overlap)
     assert sim_trim(hostsim, _fq(reads), ",".join("ACGTACGTAC" for _ in range(17))) == -1          # more than 16: refused
-    assert sim_trim(hostsim, _fq(reads), "A" * 65) == -1 and sim_trim(hostsim, _fq(reads), "ACGTRYACGT") == -1
+    assert sim_trim(hostsim, _fq(reads), "A" * 65) == -1 and sim_trim(hostsim, _fq(reads), "ACGTJACGT") == -1
+    assert sim_trim(hostsim, _fq(reads), "ACGT{3}ACGT") == -1 and sim_trim(hostsim, _fq(reads), "ACGTACGT...TTGGCCAA") == -1     # braces, linked adapters: refused
     # (3) anchored: removed only when it ends where the read ends
     ad = rs(24)
     reads = [ins[0] + ad, ins[1] + ad + b"ACGTAC", ins[2] + ad[:12], ins[3] + ad[:-1], ins[0] + ad[:10] + b"G" + ad[10:]]
@@ -145,6 +146,67 @@ def test_adapter_syntax_known_answers(hostsim):
     assert plain[0][1] == ins[1] and plain[0][2] == ins[2]                 # the same adapter without the anchor takes both
     assert otrim.adapter_back(ad, ins[0] + ad, anchored=True)[2:4] == (len(ins[0]), len(ins[0]) + 24)
     assert otrim.adapter_back(ad, ins[1] + ad + b"ACGTAC", anchored=True) is None
+
+
+IUPAC = {"A": "A", "C": "C", "G": "G", "T": "T", "R": "AG", "Y": "CT", "S": "CG", "W": "AT", "K": "GT", "M": "AC",
+         "B": "CGT", "D": "AGT", "H": "ACT", "V": "ACG", "N": "ACGT"}
+
+
+def test_adapter_wildcards_known_answers(hostsim):
+    """Adapters with IUPAC wildcard characters (cutadapt's adapter_wildcards, on by default: trim_file.py:14-23 passes the
+    string through unchanged): an adapter N matches any read base, a code matches the bases it stands for, a read N
+    matches nothing; no exact-occurrence shortcut.  Expected values by construction, and equal to the restatement."""
+    rng = np.random.default_rng(78)
+    rs = lambda n: bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n).tolist())
+    ins = [rs(22), rs(30), rs(19), rs(25), rs(33)]
+    F = rs(20)
+    spec = "NNNN" + F.decode()                                   # a random 4-mer in front of the fixed part
+    reads = [ins[0] + b"ACGT" + F + b"TTTT", ins[1] + b"GGCA" + F[:11], ins[2] + b"TNGA" + F, ins[3] + b"CC", ins[4]]
+    got = sim_trim(hostsim, _fq(reads), spec)
+    assert got[0][0] == ins[0]                      # any four bases + the fixed part: cut where the four start
+    assert got[0][1] == ins[1]                      # the read ends inside the fixed part
+    assert got[0][2] == ins[2]                      # a read N under an adapter N is a mismatch (1 <= int(24 * 0.12) = 2): still found
+    assert got[0][3] == (ins[3] + b"CC")[:-4] and got[0][4] == ins[4][:-4]      # ANY read ends in four bases that match NNNN: cutadapt's known effect of an adapter that starts with N
+    assert got[0] == otrim.trim_fastq(_fq(reads), spec)[0]
+    assert otrim.adapter_back(spec.encode(), reads[0]) == (0, 24, 22, 46, 24, 0)
+    assert otrim.adapter_back(spec.encode(), reads[2])[2:6] == (19, 43, 23, 1)
+    # a two-base code: R = A or G costs nothing for either, one error for the others
+    ad = F[:8] + b"R" + F[9:]
+    ra, rg, rc = (ins[0] + F[:8] + x + F[9:] + b"AC" for x in (b"A", b"G", b"C"))
+    assert otrim.adapter_back(ad, ra) == (0, 20, 22, 42, 20, 0) and otrim.adapter_back(ad, rg) == (0, 20, 22, 42, 20, 0)
+    assert otrim.adapter_back(ad, rc) == (0, 20, 22, 42, 19, 1)
+    got = sim_trim(hostsim, _fq([ra, rg, rc]), ad.decode().lower())
+    assert got[0] == [ins[0]] * 3 and got[0] == otrim.trim_fastq(_fq([ra, rg, rc]), ad.decode())[0]
+    # X matches nothing; anchored + wildcards
+    assert otrim.adapter_back(F[:5] + b"X" + F[6:], ins[0] + F)[5] == 1
+    got = sim_trim(hostsim, _fq([ins[0] + b"AC" + F, ins[1] + b"AC" + F + b"G"]), "NN" + F.decode() + "$")
+    assert got[0][0] == ins[0]
+    assert got[0] == otrim.trim_fastq(_fq([ins[0] + b"AC" + F, ins[1] + b"AC" + F + b"G"]), "NN" + F.decode() + "$")[0]
+
+
+@pytest.mark.parametrize("seed", [7, 8])
+def test_random_wildcard_adapters(hostsim, seed):
+    """Randomised: 1-4 adapters of 6-48 characters, a share of them IUPAC codes (N runs among them), some anchored; the
+    reads carry one concrete spelling of an adapter, with errors.  Host build of the device code against the restatement."""
+    rng = np.random.default_rng(4200 + seed)
+    libs, _ = synth.make_libraries(synth.Profile.tiny(), 77)
+    codes = "ACGT" * 6 + "RYSWKMBDHVN" + "NNNN"
+    for _ in range(8):
+        nad = int(rng.integers(1, 5))
+        ads = ["".join(codes[x] for x in rng.integers(0, len(codes), size=int(rng.integers(6, 49)))) for _ in range(nad)]
+        spec = ",".join(a + ("$" if rng.random() < 0.25 else "") for a in ads)
+        t5, t3 = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        seqs, lens = synth.make_reads(libs, 300, int(rng.integers(0, 1 << 30)))
+        lens = np.minimum(lens, rng.integers(1, 48, size=len(lens))).astype(lens.dtype)
+        use = "".join(IUPAC[c][int(rng.integers(0, len(IUPAC[c])))] for c in ads[int(rng.integers(0, nad))])
+        data = synth.make_raw_fastq(seqs, lens, int(rng.integers(0, 1 << 30)), adapter=use,
+                                    read_len=int(rng.choice([36, 50, 75, 100, 150])) if rng.random() < 0.5 else int(rng.integers(20, 60)) + len(use),
+                                    adapter_error=float(rng.random()) * 0.7, low_tail=float(rng.random()) * 0.3, odd=0.1)
+        want, total, base, reported = otrim.trim_fastq(data, spec, t5, t3)
+        got = sim_trim(hostsim, data, spec, t5, t3)
+        assert not isinstance(got, int), (got, spec)
+        assert (got[0], got[1], got[2], got[3]) == (want, total, base, reported), (spec, t5, t3)
+        assert len(set(len(x) for x in want)) > 5, spec          # the adapters were found: lengths spread like the inserts
 
 
 @pytest.mark.parametrize("seed", [5, 6])
