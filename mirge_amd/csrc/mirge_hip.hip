@@ -161,24 +161,151 @@ struct Class {
 };
 
 // Verbatim uniques (kernels.h: match_long): reads no key can hold, collapsed by their exact string as miRge.pl:306 does.
-// A host-side table -- in small-RNA data they are the odd read; a run made of nothing else (150-nt reads, --adapter none)
-// works, at the pace of a host hash map.
+// A host-side table.  In small-RNA data they are the odd read, but a run can be made of nothing else (150-nt reads,
+// --adapter none), so a batch of them is added by the host's threads: the table is cut into NSH shards by the string's
+// hash, phase 1 hashes the batch's strings (threads over slices of the batch), phase 2 gives every shard to one thread,
+// which looks its strings up in the shard's open-addressing table (64-bit hash, then the bytes) in batch order, phase 3
+// numbers what is new.  Ids and entries come out exactly as the serial loop numbers them -- by first occurrence -- because
+// "new" is a flag per batch item and the numbers are its prefix sums.
 struct Verb {
-    std::unordered_map<std::string, uint32_t> index;
+    static constexpr int NSH = 64;
+    static constexpr uint32_t NONE = 0xFFFFFFFFu, PEND = 0x80000000u;
+    struct Ent { uint64_t h; uint32_t id, tix; uint64_t epoch; };       // id: index into seq (PEND | k while its batch runs); tix: its line in the batch's touch list
+    struct Touch { uint32_t id, first, count, pos; };                      // a unique the running batch met: where first, how often, its entry
+    struct Shard {
+        std::vector<Ent> tab; size_t used = 0;
+        std::unordered_map<uint64_t, uint32_t> entry;                      // unique * S + sample -> position in the entry arrays
+        std::vector<std::string> pend; std::vector<uint32_t> pend_slot;    // the running batch's new strings
+        std::vector<Touch> touch;
+    };
+    Shard sh[NSH];
     std::vector<std::string> seq;
-    std::unordered_map<uint64_t, uint32_t> entry;              // unique * S + sample -> position in the entry arrays
     std::vector<uint32_t> coo_u, coo_s, coo_c;
     uint32_t maxlen = 0;
+    uint64_t epoch = 0;
     DevBuf pool, off, len, ann_round, ann_ref, ann_amb, d_u, d_s, d_c;
-    void reset() { index.clear(); seq.clear(); entry.clear(); coo_u.clear(); coo_s.clear(); coo_c.clear(); maxlen = 0; }
+    void reset() {
+        for (auto& x : sh) { x.tab.clear(); x.used = 0; x.entry.clear(); x.pend.clear(); x.pend_slot.clear(); x.touch.clear(); }
+        seq.clear(); coo_u.clear(); coo_s.clear(); coo_c.clear(); maxlen = 0;
+    }
     void release() { pool.release(); off.release(); len.release(); ann_round.release(); ann_ref.release(); ann_amb.release(); d_u.release(); d_s.release(); d_c.release(); }
+    static uint64_t hash(const char* s, size_t n) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, s + i, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+        uint64_t w = 0; if (i < n) memcpy(&w, s + i, n - i);
+        h = (h ^ w) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 32;
+        return h;
+    }
+    static int shard_of(uint64_t h) { return (int)(h >> 58); }             // (NSH = 64; the table slots take the low bits)
+    const std::string& str_of(const Shard& x, uint32_t id) const { return (id & PEND) ? x.pend[id & ~PEND] : seq[id]; }
+    void grow(Shard& x) {
+        const size_t cap = x.tab.empty() ? 1024 : x.tab.size() * 2;
+        std::vector<Ent> nt(cap, Ent{0, NONE, 0, 0});
+        for (const Ent& e : x.tab) if (e.id != NONE) { size_t k = (size_t)e.h & (cap - 1); while (nt[k].id != NONE) k = (k + 1) & (cap - 1); nt[k] = e; }
+        x.tab.swap(nt);
+        for (size_t k = 0; k < x.tab.size(); ++k) if (x.tab[k].id != NONE && (x.tab[k].id & PEND)) x.pend_slot[x.tab[k].id & ~PEND] = (uint32_t)k;
+    }
+    // the slot of string s in shard x (its id is NONE if the string is new: the caller fills it in)
+    size_t find(Shard& x, uint64_t h, const char* s, size_t n) {
+        if ((x.used + 1) * 2 > x.tab.size()) grow(x);
+        const size_t cap = x.tab.size();
+        size_t k = (size_t)h & (cap - 1);
+        for (;; k = (k + 1) & (cap - 1)) {
+            Ent& e = x.tab[k];
+            if (e.id == NONE) return k;
+            if (e.h == h) { const std::string& t = str_of(x, e.id); if (t.size() == n && memcmp(t.data(), s, n) == 0) return k; }
+        }
+    }
+    // one string (imports, small batches)
     void add(const char* s, size_t n, int sample, int S, uint32_t count) {
-        auto it = index.emplace(std::string(s, n), (uint32_t)seq.size());
-        if (it.second) { seq.push_back(it.first->first); if (n > maxlen) maxlen = (uint32_t)n; }
-        const uint32_t u = it.first->second;
-        auto e = entry.emplace((uint64_t)u * (uint64_t)S + (uint64_t)sample, (uint32_t)coo_u.size());
+        const uint64_t h = hash(s, n);
+        Shard& x = sh[shard_of(h)];
+        const size_t k = find(x, h, s, n);
+        if (x.tab[k].id == NONE) { x.tab[k] = Ent{h, (uint32_t)seq.size(), 0, 0}; ++x.used; seq.emplace_back(s, n); if (n > maxlen) maxlen = (uint32_t)n; }
+        const uint32_t u = x.tab[k].id;
+        auto e = x.entry.emplace((uint64_t)u * (uint64_t)S + (uint64_t)sample, (uint32_t)coo_u.size());
         if (e.second) { coo_u.push_back(u); coo_s.push_back((uint32_t)sample); coo_c.push_back(count); }
         else coo_c[e.first->second] += count;
+    }
+    // a batch of one sample's strings, once each: item(i) -> (pointer, length)
+    template <class Item> void add_batch(uint64_t n, Item item, int sample, int S, int nthr) {
+        if (n < 8192 || nthr <= 1 || n >= 0x7FFFFFFFull) { for (uint64_t i = 0; i < n; ++i) { auto it = item(i); add(it.first, it.second, sample, S, 1); } return; }
+        ++epoch;
+        auto run = [&](int nt, auto fn) { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { fn(t); }); for (auto& q : th) q.join(); };
+        // phase 1: hashes; every thread lists its slice's items by shard (in batch order)
+        std::vector<uint64_t> hs((size_t)n);
+        std::vector<std::vector<std::vector<uint32_t>>> lists((size_t)nthr, std::vector<std::vector<uint32_t>>(NSH));
+        std::vector<uint32_t> tmax((size_t)nthr, 0);
+        run(nthr, [&](int t) {
+            uint32_t mx = 0;
+            for (uint64_t i = n * t / nthr, e = n * (t + 1) / nthr; i < e; ++i) {
+                auto it = item(i);
+                const uint64_t h = hash(it.first, it.second);
+                hs[(size_t)i] = h; lists[(size_t)t][(size_t)shard_of(h)].push_back((uint32_t)i);
+                if (it.second > mx) mx = (uint32_t)it.second;
+            }
+            tmax[(size_t)t] = mx;
+        });
+        for (uint32_t m : tmax) if (m > maxlen) maxlen = m;
+        // phase 2: a shard at a time per thread; new strings and new (unique, sample) pairs are flagged per batch item
+        std::vector<uint8_t> newu((size_t)n, 0), newe((size_t)n, 0);
+        std::atomic<int> next{0};
+        run(nthr, [&](int) {
+            for (;;) {
+                const int si = next.fetch_add(1);
+                if (si >= NSH) return;
+                Shard& x = sh[si];
+                x.pend.clear(); x.pend_slot.clear(); x.touch.clear();
+                for (int t = 0; t < nthr; ++t) for (uint32_t i : lists[(size_t)t][(size_t)si]) {
+                    auto it = item(i);
+                    const size_t k = find(x, hs[i], it.first, it.second);
+                    Ent& e = x.tab[k];
+                    if (e.id == NONE) {
+                        e = Ent{hs[i], PEND | (uint32_t)x.pend.size(), 0, 0}; ++x.used;
+                        x.pend.emplace_back(it.first, it.second); x.pend_slot.push_back((uint32_t)k);
+                        newu[i] = 1;
+                    }
+                    if (e.epoch != epoch) {
+                        e.epoch = epoch; e.tix = (uint32_t)x.touch.size();
+                        uint32_t pos = NONE;
+                        if (!(e.id & PEND)) { auto f = x.entry.find((uint64_t)e.id * (uint64_t)S + (uint64_t)sample); if (f != x.entry.end()) pos = f->second; }
+                        if (pos == NONE) newe[i] = 1;
+                        x.touch.push_back(Touch{e.id, i, 0, pos});
+                    }
+                    ++x.touch[e.tix].count;
+                }
+            }
+        });
+        // phase 3: numbers = prefix sums of the flags (the order a serial loop would give), then every shard files its own
+        std::vector<uint32_t> ru((size_t)n), re((size_t)n);
+        uint32_t nu = 0, ne = 0;
+        for (uint64_t i = 0; i < n; ++i) { ru[(size_t)i] = nu; nu += newu[(size_t)i]; re[(size_t)i] = ne; ne += newe[(size_t)i]; }
+        const uint32_t u0 = (uint32_t)seq.size(), e0 = (uint32_t)coo_u.size();
+        seq.resize((size_t)u0 + nu); coo_u.resize((size_t)e0 + ne); coo_s.resize((size_t)e0 + ne); coo_c.resize((size_t)e0 + ne);
+        next = 0;
+        run(nthr, [&](int) {
+            for (;;) {
+                const int si = next.fetch_add(1);
+                if (si >= NSH) return;
+                Shard& x = sh[si];
+                for (Touch& t : x.touch) {
+                    uint32_t u = t.id;
+                    if (u & PEND) {
+                        const uint32_t k = u & ~PEND;
+                        u = u0 + ru[t.first];
+                        seq[u] = std::move(x.pend[k]);
+                        x.tab[x.pend_slot[k]].id = u;
+                    }
+                    if (t.pos == NONE) {
+                        const uint32_t pos = e0 + re[t.first];
+                        coo_u[pos] = u; coo_s[pos] = (uint32_t)sample; coo_c[pos] = t.count;
+                        x.entry.emplace((uint64_t)u * (uint64_t)S + (uint64_t)sample, pos);
+                    } else coo_c[t.pos] += t.count;
+                }
+                x.pend.clear(); x.pend_slot.clear(); x.touch.clear();
+            }
+        });
     }
 };
 
@@ -214,6 +341,7 @@ struct mirge_ctx {
     // everything a run starts from zero and hands back lives in ONE arena: [round stats | quant | iscan | categories |
     // length histogram | trimmedUniq | survivor-list lengths x 2] -- one memset before the cascade, one copy to the host after it
     DevBuf state; unsigned long long* h_state = nullptr; size_t h_state_cap = 0;
+    uint8_t* h_odd = nullptr; size_t h_odd_cap = 0;     // pinned: the verbatim reads of a FASTQ call on their way to the host table
     unsigned long long *d_stats = nullptr, *d_quant = nullptr, *d_iscan = nullptr, *d_cat = nullptr, *d_len = nullptr, *d_tu = nullptr;
     unsigned long long* h_ctr = nullptr;            // pinned, 16 words
     // results
@@ -880,7 +1008,8 @@ int collapse_host(mirge_ctx* c, const char* seqs, const uint64_t* offs, uint64_t
     // failed collapse, leaves the context as it was before the call
     int rc = collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
     if (rc) return rc;
-    for (uint64_t i : verb_later) c->vb.add(seqs + offs[i], (size_t)(offs[i + 1] - offs[i]), sample, c->S, 1);
+    c->vb.add_batch(verb_later.size(), [&](uint64_t j) { const uint64_t i = verb_later[(size_t)j]; return std::make_pair(seqs + offs[i], (size_t)(offs[i + 1] - offs[i])); },
+                    sample, c->S, nthr);
     return MIRGE_OK;
 }
 
@@ -1006,11 +1135,21 @@ int collapse_fastq_dev(mirge_ctx* c, const uint8_t* d, uint64_t size, uint8_t la
         hipLaunchKernelGGL(k_fq_odd_gather, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, c->st, d, c->fq_start.as<uint64_t>(),
                            c->fq_odd.as<uint64_t>(), m, c->fq_oddpool.as<uint8_t>(), c->fq_oddtab.as<uint64_t>(), cursor);
         HIPCHK(c, hipGetLastError());
-        std::vector<uint64_t> tab((size_t)m); std::vector<char> pool((size_t)nbytes + 1);
-        HIPCHK(c, hipMemcpyAsync(tab.data(), c->fq_oddtab.p, m * 8, hipMemcpyDeviceToHost, c->st));
-        if (nbytes) HIPCHK(c, hipMemcpyAsync(pool.data(), c->fq_oddpool.p, nbytes, hipMemcpyDeviceToHost, c->st));
+        // table + bytes into ONE pinned buffer the context keeps (pageable vectors: 4 GB/s and a zero fill; pinned: the link's rate)
+        const size_t need = (size_t)m * 8 + (size_t)nbytes + 16;
+        if (c->h_odd_cap < need) {
+            if (c->h_odd) (void)hipHostFree(c->h_odd);
+            c->h_odd = nullptr; c->h_odd_cap = 0;
+            HIPCHK(c, hipHostMalloc((void**)&c->h_odd, need + need / 4));
+            c->h_odd_cap = need + need / 4;
+        }
+        const uint64_t* tab = reinterpret_cast<const uint64_t*>(c->h_odd);
+        const char* pool = reinterpret_cast<const char*>(c->h_odd) + (size_t)m * 8;
+        HIPCHK(c, hipMemcpyAsync(c->h_odd, c->fq_oddtab.p, m * 8, hipMemcpyDeviceToHost, c->st));
+        if (nbytes) HIPCHK(c, hipMemcpyAsync(c->h_odd + (size_t)m * 8, c->fq_oddpool.p, nbytes, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
-        for (uint64_t j = 0; j < m; ++j) c->vb.add(pool.data() + (tab[(size_t)j] >> 16), (size_t)(tab[(size_t)j] & 0xFFFF), sample, c->S, 1);
+        c->vb.add_batch(m, [&](uint64_t j) { return std::make_pair(pool + (tab[(size_t)j] >> 16), (size_t)(tab[(size_t)j] & 0xFFFF)); },
+                        sample, c->S, host_threads());
     }
     uint64_t n16 = c->h_ctr[0], n48 = c->h_ctr[1];
     return collapse_packed(c, c->stage16.p, n16, c->stage48.p, n48, sample);
@@ -1723,6 +1862,7 @@ void mirge_close(mirge_ctx* c) {
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_fb) (void)hipHostFree(c->h_fb);
+    if (c->h_odd) (void)hipHostFree(c->h_odd);
     for (auto& e : c->ev_t) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_c) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);

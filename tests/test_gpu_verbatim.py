@@ -104,3 +104,43 @@ def test_refused_reads():
         ctx.reset()
         ctx.collapse_seqs(["A" * capi.MAX_READ_LEN, "acgu", "ACGT"], 0)        # the longest read the library takes
         assert ctx.n_unique() == 3
+
+
+@pytest.mark.parametrize("path", ["seqs", "fastq_mem"])
+def test_large_batches_of_verbatim_reads_threaded_equals_serial(monkeypatch, path):
+    """Tens of thousands of reads no key holds per call (150-nt reads, --adapter none): the host table takes a batch with
+    all the host's threads, a shard of the table each (mirge_hip.hip: Verb::add_batch).  Uniques, their numbering, the
+    (unique, sample) entries and the counts must be those of the serial loop (MIRGE_HOST_THREADS=1) and of a plain Counter:
+    duplicates inside a batch, across the two calls of a sample and across samples."""
+    import collections
+    rng = np.random.default_rng(77)
+    base = ["".join("ACGTacgtN."[x] for x in rng.integers(0, 10, size=int(rng.integers(125, 260)))) for _ in range(9000)]
+    def draw(n, lo, hi):
+        return [base[int(i)] for i in np.minimum(rng.zipf(1.3, size=n) - 1 + lo, hi - 1)]
+    calls = [(0, draw(30000, 0, 6000)), (0, draw(20000, 3000, 9000)), (1, draw(25000, 0, 9000))]      # (sample, reads)
+    want = [collections.Counter(), collections.Counter()]
+    for s, rd in calls:
+        want[s].update(rd)
+    exports = []
+    for nthr in ("1", "16"):
+        monkeypatch.setenv("MIRGE_HOST_THREADS", nthr)
+        with capi.Context(None, 2, 0) as ctx:
+            for s, rd in calls:
+                if path == "seqs":
+                    ctx.collapse_seqs(rd, s)
+                else:
+                    assert ctx.collapse_fastq_mem(fastq_of(rd), s) == len(rd)
+            useqs, ulens, _, _, _ = ctx.export_uniques()
+            uid, smp, cnt = ctx.export_counts()
+            order = [useqs[u, :ulens[u]].tobytes().decode() for u in range(len(ulens))]
+            exports.append((order, uid.tolist(), smp.tolist(), cnt.tolist()))
+            assert ctx.n_unique() == len(set(want[0]) | set(want[1]))
+            per = [collections.Counter(), collections.Counter()]
+            for u, s, c in zip(uid.tolist(), smp.tolist(), cnt.tolist()):
+                assert order[u] not in per[s], "a (unique, sample) pair has two entries"
+                per[s][order[u]] = c
+            assert per == want
+    # (from FASTQ text the device lists the reads no key holds in the order its threads met them: the numbering then varies
+    # from run to run whatever the host does, only the table's content is fixed)
+    if path == "seqs":
+        assert exports[0] == exports[1], "the threaded batch numbers uniques or entries differently from the serial loop"
