@@ -348,7 +348,6 @@ struct mirge_ctx {
     bool annotated = false, counts_valid = false, host_valid = false;
     uint64_t stats[MIRGE_MAX_ROUNDS][2] = {};
     uint64_t handed_on[MIRGE_MAX_ROUNDS] = {};      // per round: uniques the probe / LDS kernel handed to the generic kernel (both key classes)
-    unsigned long long* h_fb = nullptr;             // pinned: the fb list lengths of the last cascade
     double round_ms[MIRGE_MAX_ROUNDS] = {};
     std::vector<uint64_t> h_quant, h_iscan, h_cat, h_len, h_tu;
     // host copies for per-unique export
@@ -675,6 +674,21 @@ int load_ebwt(mirge_ctx* c, int lib, const std::string& base) {
 // the partitioned form (kernels.h: k_part_pass / k_part_fold) takes inputs its fixed fan-out suits: from MIRGE_PART_MIN
 // keys (default 2^20: below that the table form's launches are already latency-bound) up to 2^25 (8192 final partitions
 // of <= 4096 records); beyond, and whenever a region overruns, the table form
+// several small regions zeroed by ONE launch: a hipMemsetAsync is a launch of its own (two, when the size is not a
+// multiple of its fill width), ~10 us apart at the pace the host can queue them -- the step spent 45 us on four of them
+// before its first kernel
+struct ZeroJob { unsigned long long* p[4]; uint32_t n[4]; };      // 8-byte words
+__global__ void __launch_bounds__(256) k_zero_regions(ZeroJob J) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < J.n[r]; i += gridDim.x * 256) J.p[r][i] = 0ull;
+}
+inline void zero_regions(hipStream_t st, unsigned long long* p0, size_t n0, unsigned long long* p1 = nullptr, size_t n1 = 0,
+                         unsigned long long* p2 = nullptr, size_t n2 = 0, unsigned long long* p3 = nullptr, size_t n3 = 0) {
+    ZeroJob J{{p0, p1, p2, p3}, {(uint32_t)n0, (uint32_t)n1, (uint32_t)n2, (uint32_t)n3}};
+    const size_t mx = std::max(std::max(n0, n1), std::max(n2, n3));
+    hipLaunchKernelGGL(k_zero_regions, dim3((uint32_t)std::max<size_t>(1, std::min<size_t>(512, (mx + 255) / 256))), dim3(256), 0, st, J);
+}
 bool part_wanted(uint64_t n) {
     uint64_t lo = 1ull << 20, hi = 176000000ull;
     if (const char* e = getenv("MIRGE_PART_MIN")) lo = strtoull(e, nullptr, 10);
@@ -739,15 +753,18 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
                 C.gvalid = true;
             }
         }
-        HIPCHK(c, hipMemsetAsync(C.pt_cur.p, 0, ncur * 8, st));
-        HIPCHK(c, hipMemsetAsync(C.ws_ctr.p, 0, 64, st));
+        bool zero_ll = false;
         if (C.ll_ok) {
             for (auto& b : C.ll) HIPCHK(c, b.ensure((C.U + n) * 4, true, C.U * 4, st));
             HIPCHK(c, C.ll_ctr.ensure(LL_CSTRIDE * 16, false, 0, st));
-            if (!C.ll_fresh) { HIPCHK(c, hipMemsetAsync(C.ll_ctr.p, 0, LL_CSTRIDE * 16, st)); C.ll_fresh = true; }
+            if (!C.ll_fresh) { zero_ll = true; C.ll_fresh = true; }
         }
+        // cursors, the rank counter (+ the overflow flag beside it: word 2, so that ONE copy brings both to the host) and
+        // the length-class lists' length words
+        zero_regions(st, C.pt_cur.as<unsigned long long>(), ncur, C.ws_ctr.as<unsigned long long>(), 8,
+                     zero_ll ? C.ll_ctr.as<unsigned long long>() : nullptr, zero_ll ? (size_t)LL_CSTRIDE * 2 : 0);
         unsigned long long* cur = C.pt_cur.as<unsigned long long>();
-        unsigned long long* ovf = cur + ncur - 1;
+        unsigned long long* ovf = C.ws_ctr.as<unsigned long long>() + 2;
         kt_begin(c, "collapse_part16", st);
 #define MG_PASS1(NB) k_part_pass<NB, PT_TILE1, PT_BLOCK1>
         auto pass1 = PT_P1 <= 16 ? MG_PASS1(16) : PT_P1 <= 32 ? MG_PASS1(32) : PT_P1 <= 64 ? MG_PASS1(64) : PT_P1 <= 128 ? MG_PASS1(128) : PT_P1 <= 256 ? MG_PASS1(256) : MG_PASS1(512);      // (NB = LDS counters: any fan-out up to it)
@@ -767,8 +784,7 @@ int collapse_launch(mirge_ctx* c, Class& C, const uint64_t* d_keys, uint64_t n64
                            C.ll_ok ? C.ll[0].as<uint32_t>() : (uint32_t*)nullptr, C.ll[1].as<uint32_t>(), C.ll_ctr.as<unsigned long long>(), LL_SPLIT, CS2);
         kt_end(c, "collapse_fold16", 0, st);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(C.h_ctr, C.ws_ctr.p, 16, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipMemcpyAsync(C.h_ctr + 2, ovf, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(C.h_ctr, C.ws_ctr.p, 24, hipMemcpyDeviceToHost, st));      // rank counter words + the overflow flag
         C.pend_part = true;
         return MIRGE_OK;
     }
@@ -1607,7 +1623,8 @@ int annotate(mirge_ctx* c) {
     const size_t w_stats = MIRGE_MAX_ROUNDS * STAT_WORDS, w_cat = (size_t)5 * S, w_len = (size_t)LEN_BINS * S, w_tu = (size_t)S;
     const size_t w_act = (size_t)(MIRGE_MAX_ROUNDS + 1) * LIST_K * LIST_NSTRIDE;        // list length words of one key class: LIST_K per round, 128 B apart
     const size_t w_fb = MIRGE_MAX_ROUNDS + (MIRGE_MAX_ROUNDS + 1);                        // per class: fb list lengths, leftover-list lengths
-    const size_t w_out = w_stats + 2 * qn + w_cat + w_len + w_tu, w_all = w_out + 2 * w_act + 2 * w_fb;
+    const size_t w_res = w_stats + 2 * qn + w_cat + w_len + w_tu;                       // the results ...
+    const size_t w_out = w_res + 2 * w_fb, w_all = w_out + 2 * w_act;                   // ... + the fb list lengths: what ONE copy brings to the host
     HIPCHK(c, c->state.ensure(w_all * 8, false, 0, c->st));
     if (c->h_state_cap < w_out) {
         if (c->h_state) (void)hipHostFree(c->h_state);
@@ -1618,10 +1635,10 @@ int annotate(mirge_ctx* c) {
     c->d_stats = c->state.as<unsigned long long>();
     c->d_quant = c->d_stats + w_stats; c->d_iscan = c->d_quant + qn; c->d_cat = c->d_iscan + qn;
     c->d_len = c->d_cat + w_cat; c->d_tu = c->d_len + w_len;
-    c->cls[0].act_n = c->d_tu + w_tu; c->cls[1].act_n = c->cls[0].act_n + w_act;
-    c->cls[0].fb_n = c->cls[1].act_n + w_act; c->cls[0].fbs_n = c->cls[0].fb_n + MIRGE_MAX_ROUNDS;
+    c->cls[0].fb_n = c->d_tu + w_tu; c->cls[0].fbs_n = c->cls[0].fb_n + MIRGE_MAX_ROUNDS;
     c->cls[1].fb_n = c->cls[0].fb_n + w_fb; c->cls[1].fbs_n = c->cls[1].fb_n + MIRGE_MAX_ROUNDS;
-    HIPCHK(c, hipMemsetAsync(c->state.p, 0, w_all * 8, c->st));
+    c->cls[0].act_n = c->cls[1].fb_n + w_fb; c->cls[1].act_n = c->cls[0].act_n + w_act;
+    zero_regions(c->st, c->state.as<unsigned long long>(), w_all);
     hipEvent_t e0 = c->ev_t[0], e1 = c->ev_t[1], e2 = c->ev_t[2];
     if (c->timing) HIPCHK(c, hipEventRecord(e0, c->st));
     // the 48-byte class (reads with N or longer than 56 nt: a fraction of a percent) runs its cascade on st2 beside
@@ -1653,10 +1670,9 @@ int annotate(mirge_ctx* c) {
     { int rj = join_st2(c); if (rj) return rj; }
     if (c->timing) HIPCHK(c, hipEventRecord(e2, c->st));
     HIPCHK(c, hipMemcpyAsync(c->h_state, c->state.p, w_out * 8, hipMemcpyDeviceToHost, c->st));
-    if (!c->h_fb) HIPCHK(c, hipHostMalloc((void**)&c->h_fb, 2 * (2 * MIRGE_MAX_ROUNDS + 1) * 8));
-    HIPCHK(c, hipMemcpyAsync(c->h_fb, c->cls[0].fb_n, 2 * w_fb * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
-    for (int r = 0; r < MIRGE_MAX_ROUNDS; ++r) c->handed_on[r] = c->h_fb[r] + c->h_fb[w_fb + r];
+    const unsigned long long* h_fb = c->h_state + w_res;
+    for (int r = 0; r < MIRGE_MAX_ROUNDS; ++r) c->handed_on[r] = h_fb[r] + h_fb[w_fb + r];
     if (c->cls[0].pending || c->cls[1].pending) {
         // a fused call: the collapse was queued in front of all this and is settled only now
         bool reran = false;
@@ -1668,7 +1684,7 @@ int annotate(mirge_ctx* c) {
     c->h_quant.assign(hraw + w_stats, hraw + w_stats + qn); c->h_iscan.assign(hraw + w_stats + qn, hraw + w_stats + 2 * qn);
     c->h_cat.assign(hraw + w_stats + 2 * qn, hraw + w_stats + 2 * qn + w_cat);
     c->h_len.assign(hraw + w_stats + 2 * qn + w_cat, hraw + w_stats + 2 * qn + w_cat + w_len);
-    c->h_tu.assign(hraw + w_out - w_tu, hraw + w_out);
+    c->h_tu.assign(hraw + w_res - w_tu, hraw + w_res);
     float ms = 0;
     c->annotate_ms = 0; c->counts_ms = 0;
     if (c->timing) { (void)hipEventElapsedTime(&ms, e0, e1); c->annotate_ms = ms; (void)hipEventElapsedTime(&ms, e1, e2); c->counts_ms = ms; }
@@ -1861,7 +1877,6 @@ void mirge_close(mirge_ctx* c) {
     for (auto& k : c->kt) { if (k.a) (void)hipEventDestroy(k.a); if (k.b) (void)hipEventDestroy(k.b); }
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_state) (void)hipHostFree(c->h_state);
-    if (c->h_fb) (void)hipHostFree(c->h_fb);
     if (c->h_odd) (void)hipHostFree(c->h_odd);
     for (auto& e : c->ev_t) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_c) if (e) (void)hipEventDestroy(e);
