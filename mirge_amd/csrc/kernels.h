@@ -2197,7 +2197,13 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
     __syncthreads();
 
     // ---- drain: lane = (chunk, entry); every chunk's owner is told through LDS
-    auto judge = [&](uint32_t meta, uint32_t at) {
+    // one list entry against its owner's read: the three order keys of the alignment, 0 = none.  The 64 lanes of a step
+    // of the long queue share ONE owner: they fold their keys by shuffles first and one lane tells the owner -- on
+    // libraries with repeated sequences (families of near-identical members) most entries of a list verify, and 64 LDS
+    // atomics on one word are served one after the other (bench.py `repeats`: round 3 1.81 -> 0.96 ms).
+    auto judge = [&](bool go, uint32_t meta, uint32_t at, unsigned long long& x, unsigned long long& y, unsigned long long& z) {
+        x = 0; y = 0; z = 0;
+        if (!go) return;
         const uint32_t owner = meta & 255;
         ProbeRead O;
         O.r[0] = s_r0[owner]; O.r[1] = s_r1[owner];
@@ -2207,17 +2213,36 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
         probe_masks(O);
         int f, sm, tm; uint32_t w, ref;
         if (probe_verify<KW == 6>(P, O, (int)((meta >> 20) & 31), (int)((meta >> 14) & 63), e, f, sm, tm, w, ref)) {
-            atomicMax(&s_best[owner], (unsigned long long)hit_score(sm, tm, w, f));
-            atomicMax(&s_best[PB + owner], (unsigned long long)hit_kmax(sm, ref));
-            atomicMax(&s_best[2 * PB + owner], (unsigned long long)hit_kmin(sm, ref));
+            x = hit_score(sm, tm, w, f); y = hit_kmax(sm, ref); z = hit_kmin(sm, ref);
         }
+    };
+    auto fold_max = [&](unsigned long long& v, int width) {       // max over aligned groups of `width` lanes
+        for (int o = 1; o < width; o <<= 1) { const unsigned long long t = __shfl_xor(v, o); v = t > v ? t : v; }
+    };
+    auto tell = [&](uint32_t owner, unsigned long long x, unsigned long long y, unsigned long long z) {
+        if (!x) return;
+        atomicMax(&s_best[owner], x); atomicMax(&s_best[PB + owner], y); atomicMax(&s_best[2 * PB + owner], z);
     };
     {
         const uint32_t qn = s_qn4 < (uint32_t)PQ4 ? s_qn4 : (uint32_t)PQ4;
         for (uint32_t base = (tid >> 6) * 16; base < qn; base += (PB / 64) * 16) {
             const uint32_t j = base + (lane >> 2), ei = lane & 3;
             const uint32_t meta = j < qn ? s_q4meta[j] : 0u;
-            if ((meta >> 31) && ei <= ((meta >> 8) & 63)) judge(meta, s_q4lo[j] + ei);
+            if ((meta >> 31) && ei <= ((meta >> 8) & 63)) {       // (short lists: at most 4 lanes of a step share an owner -- told directly)
+                const uint32_t owner = meta & 255;
+                ProbeRead O;
+                O.r[0] = s_r0[owner]; O.r[1] = s_r1[owner];
+                O.l = (int)(s_ls[owner] & 255); O.s = (int)((s_ls[owner] >> 8) & 255);
+                O.nraw = KW == 6 ? s_nm[owner] : 0ull;
+                const PEnt e = load_pent(L.pent, s_q4lo[j] + ei);
+                probe_masks(O);
+                int f, sm, tm; uint32_t w, ref;
+                if (probe_verify<KW == 6>(P, O, (int)((meta >> 20) & 31), (int)((meta >> 14) & 63), e, f, sm, tm, w, ref)) {
+                    atomicMax(&s_best[owner], (unsigned long long)hit_score(sm, tm, w, f));
+                    atomicMax(&s_best[PB + owner], (unsigned long long)hit_kmax(sm, ref));
+                    atomicMax(&s_best[2 * PB + owner], (unsigned long long)hit_kmin(sm, ref));
+                }
+            }
         }
         // a 64-entry chunk has ONE owner: the wave takes the owner's read into scalar registers (readfirstlane) and
         // walks the list through its 8-byte pre-filter words first -- a lane's share is one 8-byte load, XOR and a
@@ -2239,7 +2264,18 @@ k_probe_round(const uint64_t* __restrict__ ukeys, uint32_t U, uint8_t* ann_round
             const uint32_t ls = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ls[owner]);
             uint64_t rr, pm;
             pre_query(u0, u1, (int)(ls & 255), (int)((meta >> 14) & 63), rr, pm);
-            if (lane <= ((meta >> 8) & 63) && pre_mism(rr, pm, L.ppre[lo + lane]) <= P.maxmm) judge(meta, lo + lane);
+            unsigned long long x, y, z;
+            judge(lane <= ((meta >> 8) & 63) && pre_mism(rr, pm, L.ppre[lo + lane]) <= P.maxmm, meta, lo + lane, x, y, z);
+            if (__any(x != 0)) {
+                // the wave's best alignment, then the largest and the smallest reference among the lanes of ITS stratum
+                // (what the maxima of hit_kmax / hit_kmin over all lanes come to): one 64-bit and two 32-bit folds
+                unsigned long long bx = x;
+                fold_max(bx, 64);
+                const bool in = x != 0 && (x >> 36) == (bx >> 36);
+                uint32_t rmx = in ? (uint32_t)y : 0u, rmn = in ? (uint32_t)z : 0u;       // (z holds 0xFFFFFFFF - ref)
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_xor(rmx, o), b = __shfl_xor(rmn, o); rmx = a > rmx ? a : rmx; rmn = b > rmn ? b : rmn; }
+                if (lane == 0) tell(owner, bx, ((bx >> 36) << 32) | rmx, ((bx >> 36) << 32) | rmn);
+            }
         }
     }
     __syncthreads();
