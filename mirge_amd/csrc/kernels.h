@@ -2058,7 +2058,7 @@ template <int NS> struct ProbeQ { static constexpr int Q4 = MG_PQ4, Q64 = MG_PQ6
 #define MG_PROBE_WAVES3 6                       // several schemes, of unequal blocks (the two-mismatch round): 56 B of scratch at 7 waves, none at 6 -- round 5 0.47 -> 0.40 ms
 #endif
 #ifndef MG_PROBE_WAVES0
-#define MG_PROBE_WAVES0 8                       // the scheme-free instantiation (rounds 1 and 4 of the reference cascade) fits 64 registers but for 16 B of scratch
+#define MG_PROBE_WAVES0 7                       // the scheme-free instantiation (rounds 1 and 4 of the reference cascade): 72 registers, no scratch (8 waves: 64 registers + 20 B of scratch since the long-list fold, rounds 1 / 4 0.127 / 0.312 ms against 0.121 / 0.290; 6 waves: 0.14 / 0.30)
 #endif
 // chunk: lo = first entry; meta = owner (0-7) | entries - 1 (8-13) | ps (14-19) | K (20-24) | written (31)
 MG_HD uint32_t chunk_meta(uint32_t owner, uint32_t cnt, int ps, int K) {
