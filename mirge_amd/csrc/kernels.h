@@ -2720,7 +2720,7 @@ constexpr int CNT_LDS_M = 3584;        // 2 x 3584 x 8 B = 56 KB of dynamic LDS 
 // dynamic LDS: 2 * M words when M <= CNT_LDS_M (the quant and iscan columns), else none -- a human-sized miRNA library
 // (2.7 k names) takes 43 KB and three blocks fit a CU, where a fixed 6144-name array held one
 template <int KW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_counts(const uint32_t* __restrict__ coo_g, const uint32_t* __restrict__ coo_c, uint32_t n, int sample, int S,
          const uint64_t* __restrict__ ukeys, const uint8_t* __restrict__ ann_round, const int32_t* __restrict__ ann_ref,
          int M, uint32_t round_libs, uint32_t iscan_rounds, unsigned long long* quant, unsigned long long* iscan,

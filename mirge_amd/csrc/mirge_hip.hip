@@ -1510,6 +1510,7 @@ int annotate_class(mirge_ctx* c, Class& C, int r, const mirge_round& R) {
 }
 
 // fewer entries than this: global atomics, no LDS columns (kernels.h: k_counts).  MIRGE_CNT_LDS_MIN: tests put the LDS form on small inputs
+inline uint32_t counts_block() { if (const char* e = getenv("MIRGE_CNT_BLOCK")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) return (uint32_t)v; } return 1024; }      // (A/B aid)
 inline uint64_t cnt_lds_min() { if (const char* e = getenv("MIRGE_CNT_LDS_MIN")) return strtoull(e, nullptr, 10); return 1u << 18; }
 template <int KW>
 int counts_class(mirge_ctx* c, Class& C, int M) {
@@ -1520,9 +1521,12 @@ int counts_class(mirge_ctx* c, Class& C, int M) {
     for (auto& sg : C.segs) {
         if (!sg.count) continue;
         const size_t lds = (M <= CNT_LDS_M && sg.count >= CNT_LDS_MIN_ENTRIES) ? (size_t)2 * M * 8 : 0;
-        const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (150u << 10) / (lds + 2048)));      // blocks a CU's LDS holds
-        uint32_t grid = (uint32_t)std::min<uint64_t>(256 * per_cu, (sg.count + 255) / 256);
-        hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(256), lds, C.st, C.coo_g.as<uint32_t>() + sg.start,
+        // with the columns in LDS (42 KB at a human-sized library) three blocks fit a CU: blocks of 1024 threads then, so
+        // that the CU still runs 2048 of them (blocks of 256: 3 waves per SIMD, 0.118 ms; 512: 0.09; 1024: 0.072)
+        const uint32_t cb = lds ? counts_block() : 256u;
+        const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(2048 / cb, (150u << 10) / (lds + 2048)));      // blocks a CU holds
+        uint32_t grid = (uint32_t)std::min<uint64_t>(256 * per_cu, (sg.count + cb - 1) / cb);
+        hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(cb), lds, C.st, C.coo_g.as<uint32_t>() + sg.start,
                            C.coo_c.as<uint32_t>() + sg.start, (uint32_t)sg.count, sg.sample, c->S, C.ukeys.as<uint64_t>(),
                            C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), M, round_libs, iscan_rounds,
                            c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu, (const unsigned long long*)nullptr, lds != 0);
@@ -1530,9 +1534,10 @@ int counts_class(mirge_ctx* c, Class& C, int M) {
     if (C.pending && C.pend_n) {
         // the sample of a deferred collapse: its entries follow the settled ones, how many there are the kernel reads itself
         const size_t lds = (M <= CNT_LDS_M && C.pend_n >= CNT_LDS_MIN_ENTRIES) ? (size_t)2 * M * 8 : 0;
-        const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (150u << 10) / (lds + 2048)));
-        uint32_t grid = (uint32_t)std::min<uint64_t>(256 * per_cu, ((uint64_t)C.pend_n + 255) / 256);
-        hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(256), lds, C.st, C.coo_g.as<uint32_t>() + C.coo_n,
+        const uint32_t cb = lds ? counts_block() : 256u;
+        const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(2048 / cb, (150u << 10) / (lds + 2048)));
+        uint32_t grid = (uint32_t)std::min<uint64_t>(256 * per_cu, ((uint64_t)C.pend_n + cb - 1) / cb);
+        hipLaunchKernelGGL((k_counts<KW>), dim3(grid), dim3(cb), lds, C.st, C.coo_g.as<uint32_t>() + C.coo_n,
                            C.coo_c.as<uint32_t>() + C.coo_n, C.pend_n, C.pend_sample, c->S, C.ukeys.as<uint64_t>(),
                            C.ann_round.as<uint8_t>(), C.ann_ref.as<int32_t>(), M, round_libs, iscan_rounds,
                            c->d_quant, c->d_iscan, c->d_cat, c->d_len, c->d_tu, C.ws_ctr.as<unsigned long long>(), lds != 0);
