@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised cascades on the GPU against the CPU oracle, many seeds (run on the GPU box):
    python tools/fuzz_cascades.py [first_seed] [n_seeds]
-Each seed runs the three randomised parity tests of tests/ -- generic kernel only, every library with slot tables
-(k-mer length swept), and cascades that mix both kinds of round -- with that seed.  Prints one line per mismatch."""
+Each seed runs the randomised parity tests of tests/ -- generic kernel only, every library with slot tables (k-mer
+length swept; probe kernel and LDS path) and cascades that mix both kinds of round -- with that seed.  Prints one line per mismatch."""
 import os
 import sys
 
@@ -21,8 +21,9 @@ def main():
     bad = 0
     for seed in range(first, first + count):
         cases = [("generic", lambda: tp.test_random_cascades_vs_oracle(orc, seed)),
-                 ("slots kb=%d" % (6 + seed % 7), lambda: tq.test_random_cascades_through_slot_tables(orc, mp, seed, 6 + seed % 7)),
-                 ("mixed", lambda: tq.test_cascades_that_mix_probe_and_generic_rounds(orc, mp, seed))]
+                 ("slots kb=%d" % (6 + seed % 7), lambda: tq.test_random_cascades_through_slot_tables(orc, mp, seed, 6 + seed % 7, "0")),
+                 ("slots kb=%d lds" % (6 + seed % 7), lambda: tq.test_random_cascades_through_slot_tables(orc, mp, seed, 6 + seed % 7, "1")),
+                 ("mixed", lambda: tq.test_cascades_that_mix_probe_and_generic_rounds(orc, mp, seed, str(seed & 1)))]
         for name, fn in cases:
             try:
                 fn()
