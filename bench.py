@@ -283,7 +283,7 @@ def main():
     # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is the
     # builder's rocprofv3 pass over this same command (committed file), and it is reported only when that file says it was
     # taken from the same workload AND the same build of the library (sha256 of the .so); else null
-    traffic, traffic_source = None, None
+    traffic, traffic_source, requests = None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -293,13 +293,20 @@ def main():
             sha = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]
             if tj.get("reads") == N and tj.get("profile") == args.profile and tj.get("lib_sha16") == sha:
                 traffic = tj.get("kernels", {}).get(dom)
+                raw = tj.get("raw_fetch", {}).get(dom)
+                if raw and dom_ms > 0:
+                    # the same counters read as REQUESTS past the L2 (FETCH_SIZE counts 64 B for one that goes to HBM): the bound of
+                    # the index kernels is how many of those the memory system serves per second, not bytes
+                    requests = {"past_l2": int(raw // 64), "rate_G_per_s": raw / 64 / (dom_ms * 1e-3) / 1e9,
+                                "machine_random_fetch_G_per_s": {"512 MB table": 55.3, "8 GB table": 41.2, "Infinity-Cache-resident (8 MB)": 118.4},
+                                "source": "raw FETCH_SIZE of the same PMC pass / 64 B / the kernel's HIP-event time; machine rates: profiles/r02/micro_random_lines.txt"}
                 traffic_source = ("profiles/pmc_traffic.json: the builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command with "
                                   "this build of the library (lib_sha16 %s), not counters of this run; 2*FETCH + WRITE KiB, i.e. bytes past "
                                   "the L2 -- Infinity Cache hits included" % sha)
             else:
                 traffic_source = "profiles/pmc_traffic.json is of another build or workload: not reported"
         except Exception:
-            traffic, traffic_source = None, None
+            traffic, traffic_source, requests = None, None, None
     dev_ms_avg, dev_ms_med = float(np.mean(dev_ms)), float(np.median(dev_ms))
 
     if world == 1:
@@ -325,7 +332,7 @@ def main():
                    "parallelism": "shard%d%s%s" % (world, "+merge_uniques" if merge else "", "+gloo_one_device_rehearsal" if rehearsal and world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "copy_measured": copy_gbs, "frac_of_copy": achieved / copy_gbs,
+                     "requests": requests, "copy_measured": copy_gbs, "frac_of_copy": achieved / copy_gbs,
                      "kernel_ms": dom_ms, "kernel_bytes_alg": dom_bytes,
                      "note": "achieved = SURVEY.md 8d's algorithmic bytes of the kernel / its HIP-event time: an index-based matcher cannot "
                              "reach that floor.  What bounds the kernel on the machine is the rate of random 128-B line fetches past the L2 "
